@@ -1,0 +1,618 @@
+"""ORACLE — CPU restatement (numpy) of the Stylish-TTS inference hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``stylish_tts_amd/`` may import this file;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do,
+and there only as the checker / the timed CPU baseline.  The product path is the HIP
+library and fails loudly when it is missing.
+
+Parity pin: every function here is checked against golden vectors produced by running
+the reference itself in the build container (``tests/golden/gen_golden.py`` →
+``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``).  The reference holds
+no tests, fixtures or known-answer vectors of its own, so those goldens are
+the pin.  Layouts follow the reference (channel-major ``[B, C, T]``) so each function reads
+like the code it restates; file:line citations are relative to
+``/root/reference/src/stylish_tts/``.
+
+Third-party arithmetic: all reference kernels are ``torch`` ops (pinned 2.8.0 in
+``uv.lock``; goldens generated with the container's 2.10.0+rocm7.0, recorded in each
+fixture).  FFTs here run in float64 (numpy pocketfft) and are cast to float32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+F32 = np.float32
+W = Dict[str, np.ndarray]
+
+CLASS_TO_DUR = np.array([1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46], F32)  # train/utils.py:391-393
+
+
+# --------------------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------------------
+def sub(w: W, prefix: str) -> W:
+    n = len(prefix)
+    return {k[n:]: v for k, v in w.items() if k.startswith(prefix)}
+
+
+def weight_norm(g: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """w = g * v / ||v||, norm over every dim but 0 (torch weight_norm, dim=0)."""
+    nrm = np.sqrt((v.astype(np.float64) ** 2).reshape(v.shape[0], -1).sum(1)).astype(F32)
+    return (v * (g.reshape(-1) / nrm).reshape((-1,) + (1,) * (v.ndim - 1))).astype(F32)
+
+
+def wn_param(w: W, p: str) -> np.ndarray:
+    """parametrization flavour: original0 = g, original1 = v (models/decoder.py:35-45)."""
+    return weight_norm(w[p + ".parametrizations.weight.original0"], w[p + ".parametrizations.weight.original1"])
+
+
+def wn_legacy(w: W, p: str) -> np.ndarray:
+    """legacy flavour: weight_g / weight_v (models/flow.py:40,52,60)."""
+    return weight_norm(w[p + ".weight_g"], w[p + ".weight_v"])
+
+
+def conv1d(x, wt, b=None, padding=0, dilation=1, groups=1):
+    """F.conv1d, stride 1.  x [B,Cin,T], wt [Cout,Cin/groups,K]."""
+    B, Cin, T = x.shape
+    Cout, Cg, K = wt.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (padding, padding))) if padding else x
+    Tout = T + 2 * padding - dilation * (K - 1)
+    y = np.zeros((B, Cout, Tout), F32)
+    if groups == 1:
+        wk = np.ascontiguousarray(wt.transpose(2, 0, 1))  # [K, Cout, Cin]: contiguous taps → BLAS sgemm
+        for i in range(B):
+            xb = np.ascontiguousarray(xp[i])
+            for k in range(K):
+                y[i] += wk[k] @ xb[:, k * dilation : k * dilation + Tout]
+    else:
+        assert groups == Cin == Cout and Cg == 1
+        for k in range(K):
+            y += wt[None, :, 0, k, None] * xp[:, :, k * dilation : k * dilation + Tout]
+    if b is not None:
+        y += b[None, :, None]
+    return y.astype(F32)
+
+
+def linear(x, wt, b=None):
+    y = np.matmul(x, wt.T)
+    if b is not None:
+        y = y + b
+    return y.astype(F32)
+
+
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm1d(affine=False): per (b,c) over time, biased variance (models/ada_norm.py:132)."""
+    x64 = x.astype(np.float64)
+    m = x64.mean(-1, keepdims=True)
+    v = x64.var(-1, keepdims=True)
+    return ((x64 - m) / np.sqrt(v + eps)).astype(F32)
+
+
+def layer_norm_last(x, eps):
+    x64 = x.astype(np.float64)
+    m = x64.mean(-1, keepdims=True)
+    v = x64.var(-1, keepdims=True)
+    return ((x64 - m) / np.sqrt(v + eps)).astype(F32)
+
+
+def leaky_relu(x, slope=0.2):
+    return np.where(x >= 0, x, x * F32(slope)).astype(F32)
+
+
+def silu(x):
+    return (x / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
+
+
+def gelu(x):
+    from scipy.special import erf
+
+    x64 = x.astype(np.float64)
+    return (0.5 * x64 * (1.0 + erf(x64 / math.sqrt(2.0)))).astype(F32)
+
+
+def sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
+
+
+def sequence_mask(lengths, max_len):
+    """train/utils.py:52-56."""
+    return np.arange(max_len)[None, :] < np.asarray(lengths)[:, None]
+
+
+# --------------------------------------------------------------------------------------
+# AdaIN / AdaLN and the AdaIN residual block  (rows 9)
+# --------------------------------------------------------------------------------------
+def adaptive_instance(x, s, w: W, p: str):
+    """AdaptiveInstance.forward (models/ada_norm.py:135-139)."""
+    h = linear(s, w[p + ".fc.weight"], w[p + ".fc.bias"])
+    C = x.shape[1]
+    gamma, beta = h[:, :C, None], h[:, C:, None]
+    return ((1 + gamma) * instance_norm(x) + beta).astype(F32)
+
+
+def adaptive_layer_norm(x_btc, s, w: W, p: str, eps=1e-5):
+    """AdaptiveLayerNorm.forward on [B,T,C] (models/ada_norm.py:193-201)."""
+    h = linear(s, w[p + ".fc.weight"], w[p + ".fc.bias"])
+    C = x_btc.shape[-1]
+    gamma, beta = h[:, None, :C], h[:, None, C:]
+    return ((1 + gamma) * layer_norm_last(x_btc, eps) + beta).astype(F32)
+
+
+def adaptive_decoder_block(x, s, w: W, p: str):
+    """AdaptiveDecoderBlock.forward (models/ada_norm.py:166-182): AdaIN→LeakyReLU(0.2)→conv k3, twice,
+    plus (learned 1x1 | identity) shortcut, divided by sqrt(2)."""
+    h = adaptive_instance(x, s, w, p + ".norm1")
+    h = conv1d(leaky_relu(h), wn_param(w, p + ".conv1"), w[p + ".conv1.bias"], padding=1)
+    h = adaptive_instance(h, s, w, p + ".norm2")
+    h = conv1d(leaky_relu(h), wn_param(w, p + ".conv2"), w[p + ".conv2.bias"], padding=1)
+    if (p + ".conv1x1.parametrizations.weight.original0") in w:
+        sc = conv1d(x, wn_param(w, p + ".conv1x1"))
+    else:
+        sc = x
+    return ((h + sc) / F32(math.sqrt(2))).astype(F32)
+
+
+def adaptive_generator_block(x, s, w: W, p: str, kernel=7, dilations=(1, 3, 5)):
+    """AdaptiveGeneratorBlock.forward (HiFi-GAN MRF + Snake; models/ada_norm.py:109-120)."""
+    for i, d in enumerate(dilations):
+        a1, a2 = w[p + f"alpha1.{i}"], w[p + f"alpha2.{i}"]
+        xt = adaptive_instance(x, s, w, p + f"adain1.{i}")
+        xt = xt + (1 / a1) * np.sin(a1 * xt) ** 2
+        xt = conv1d(xt.astype(F32), wn_param(w, p + f"convs1.{i}"), w[p + f"convs1.{i}.bias"], padding=(kernel * d - d) // 2, dilation=d)
+        xt = adaptive_instance(xt, s, w, p + f"adain2.{i}")
+        xt = xt + (1 / a2) * np.sin(a2 * xt) ** 2
+        xt = conv1d(xt.astype(F32), wn_param(w, p + f"convs2.{i}"), w[p + f"convs2.{i}.bias"], padding=(kernel - 1) // 2)
+        x = (xt + x).astype(F32)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Decoder (row 8)
+# --------------------------------------------------------------------------------------
+def decoder_forward(asr, f0_curve, n_curve, s, w: W, p: str = "decoder."):
+    """Decoder.forward (models/decoder.py:47-60)."""
+    F0 = conv1d(f0_curve[:, None, :], wn_param(w, p + "F0_conv"), w[p + "F0_conv.bias"], padding=1)
+    N = conv1d(n_curve[:, None, :], wn_param(w, p + "N_conv"), w[p + "N_conv.bias"], padding=1)
+    x = np.concatenate([asr, F0, N], axis=1)
+    x = adaptive_decoder_block(x, s, w, p + "encode")
+    asr_res = conv1d(asr, wn_param(w, p + "asr_res.0"), w[p + "asr_res.0.bias"])
+    for i in range(4):
+        x = np.concatenate([x, asr_res, F0, N], axis=1)
+        x = adaptive_decoder_block(x, s, w, p + f"decode.{i}")
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# stochastic prior + reverse flow (rows 10-12)
+# --------------------------------------------------------------------------------------
+def prior_encoder(x, noise, w: W, p: str = "prior_encoder."):
+    """PriorEncoder.forward (models/flow.py:311-315) with the randn_like draw made explicit."""
+    xt = x.transpose(0, 2, 1)
+    mean = linear(xt, w[p + "proj_mean.weight"], w[p + "proj_mean.bias"]).transpose(0, 2, 1)
+    logstd = linear(xt, w[p + "proj_logstd.weight"], w[p + "proj_logstd.bias"]).transpose(0, 2, 1)
+    z = mean + noise * np.exp(logstd)
+    return z.astype(F32), mean, logstd
+
+
+def wn_forward(x, g, w: W, p: str, hidden=128, n_layers=4, k=5):
+    """WN.forward (models/flow.py:63-88); x_mask is the scalar 1 on the inference path."""
+    output = np.zeros_like(x)
+    gc = linear(g.transpose(0, 2, 1), wn_legacy(w, p + "cond_layer"), w[p + "cond_layer.bias"]).transpose(0, 2, 1)  # [B, 2H*L, 1]
+    for i in range(n_layers):
+        x_in = conv1d(x, wn_legacy(w, p + f"in_layers.{i}"), w[p + f"in_layers.{i}.bias"], padding=(k - 1) // 2)
+        g_l = gc[:, i * 2 * hidden : (i + 1) * 2 * hidden, :]
+        a = x_in + g_l
+        acts = (np.tanh(a[:, :hidden].astype(np.float64)) * sigmoid(a[:, hidden:]).astype(np.float64)).astype(F32)  # flow.py:7-14
+        rs = linear(acts.transpose(0, 2, 1), wn_legacy(w, p + f"res_skip_layers.{i}"), w[p + f"res_skip_layers.{i}.bias"]).transpose(0, 2, 1)
+        if i < n_layers - 1:
+            x = (x + rs[:, :hidden]).astype(F32)
+            output = output + rs[:, hidden:]
+        else:
+            output = output + rs
+    return output.astype(F32)
+
+
+def flow_reverse(z, cond, w: W, p: str = "flow.", n_flows=8):
+    """ResidualCouplingBlock.forward(reverse=True) (models/flow.py:132-151) for the z stream only
+    (mean/logstd streams are unused when audio_gt is None, speech_predictor.py:110-111).
+    reversed(flows) = Flip, layer n-1, Flip, layer n-2, …, Flip, layer 0."""
+    half = z.shape[1] // 2
+    z0, z1 = z[:, :half], z[:, half:]
+    for f in reversed(range(n_flows)):
+        z0, z1 = z1, z0  # Flip (flow.py:221-226)
+        q = p + f"flows.{2 * f}."
+        h = linear(z0.transpose(0, 2, 1), w[q + "pre.weight"], w[q + "pre.bias"]).transpose(0, 2, 1)
+        h = wn_forward(h, cond, w, q + "enc.")
+        ht = h.transpose(0, 2, 1)
+        m = linear(ht, w[q + "proj_mean.weight"], w[q + "proj_mean.bias"]).transpose(0, 2, 1)
+        ls = linear(ht, w[q + "proj_logstd.weight"], w[q + "proj_logstd.bias"]).transpose(0, 2, 1)
+        z1 = ((z1 - m) * np.exp(-ls)).astype(F32)  # flow.py:209
+    return np.concatenate([z0, z1], axis=1)
+
+
+def post_flow(z, w: W):
+    """speech_predictor.py:60-62,111."""
+    return linear(z.transpose(0, 2, 1), w["post_flow.weight"], w["post_flow.bias"]).transpose(0, 2, 1)
+
+
+# --------------------------------------------------------------------------------------
+# harmonic source, STFT, vocoder body, iSTFT (rows 13-16)
+# --------------------------------------------------------------------------------------
+def generate_pcph(f0, src_noise, init_phase, hop=75, sr=24000, noise_amplitude=0.01, power_factor=0.1):
+    """generate_pcph (models/generator.py:247-315), bound with hop_length=75, sample_rate=24000
+    (generator.py:369-373); voiced = (pitch > 10) (generator.py:405).  f0 [B,1,frames]."""
+    B, _, frames = f0.shape
+    f0 = f0.astype(F32)
+    noise = (F32(noise_amplitude) * src_noise).astype(F32)
+    vuv = f0 > 10.0
+    if not vuv.any():
+        return noise
+    sel = f0[f0 > 20]
+    if sel.size == 0:
+        raise RuntimeError("min(): voiced frames present but no f0 above 20 Hz (generator.py:285)")
+    min_f0 = float(sel.min())
+    K = min(16, int((sr / 2) / min_f0))
+    n_harm = np.ones_like(f0)
+    n_harm[vuv] = F32(sr / 2.0) / f0[vuv]
+    idx = np.arange(1, K + 1).reshape(1, -1, 1)
+    harmonic_f0 = f0 * idx.astype(F32)
+    mask = np.repeat(harmonic_f0 <= F32(sr / 2.0), hop, axis=2)
+    amp = np.repeat((vuv * F32(power_factor) * np.sqrt(F32(2.0) / n_harm)).astype(F32), hop, axis=2)
+    rad = np.repeat(f0, hop, axis=2).astype(np.float64) / sr
+    rad[..., 0] += float(np.asarray(init_phase).reshape(-1)[0])
+    rad = np.cumsum(rad, axis=2)
+    harm = np.sin(2.0 * np.pi * rad * idx).astype(F32)
+    harm = (mask * harm).sum(axis=1, keepdims=True, dtype=F32)
+    return (amp * harm + noise).astype(F32)
+
+
+def hann_periodic(n):
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n))
+
+
+def stft_transform(x, n_fft=2048, hop=75, win=1200):
+    """TorchSTFT.transform (models/generator.py:32-44): torch.stft(center=True, reflect pad, periodic Hann
+    zero-padded centrally to n_fft) → |X|, Re/(|X|+1e-9), Im/(|X|+1e-9).  x [B, L] → [B, n_fft/2+1, 1+L//hop]."""
+    B, L = x.shape
+    pad = n_fft // 2
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pad, pad)), mode="reflect")
+    nfr = 1 + L // hop
+    wfull = np.zeros(n_fft)
+    lo = (n_fft - win) // 2
+    wfull[lo : lo + win] = hann_periodic(win).astype(F32)
+    idx = np.arange(nfr)[:, None] * hop + np.arange(n_fft)[None, :]
+    frames = xp[:, idx] * wfull  # [B, nfr, n_fft]
+    X = np.fft.rfft(frames, axis=-1).transpose(0, 2, 1)  # [B, bins, nfr]
+    Xc = X.astype(np.complex64)
+    mag = np.abs(Xc).astype(F32)
+    return mag, (Xc.real / (mag + F32(1e-9))).astype(F32), (Xc.imag / (mag + F32(1e-9))).astype(F32)
+
+
+def istft(spec_mag, cx, sy, n_fft=2048, hop=75, win=1200):
+    """TorchSTFT.inverse (models/generator.py:46-56): torch.istft(center=True): irfft, window, overlap-add,
+    divide by the window-square envelope, trim n_fft/2 at both ends.  Inputs [B, bins, frames]."""
+    B, bins, nfr = spec_mag.shape
+    X = spec_mag.astype(np.float64) * (cx.astype(np.float64) + 1j * sy.astype(np.float64))
+    y = np.fft.irfft(X.transpose(0, 2, 1), n=n_fft, axis=-1)  # [B, nfr, n_fft]; imag of DC/Nyquist ignored
+    wfull = np.zeros(n_fft)
+    lo = (n_fft - win) // 2
+    wfull[lo : lo + win] = hann_periodic(win).astype(F32)
+    y = y * wfull
+    total = n_fft + hop * (nfr - 1)
+    out = np.zeros((B, total))
+    env = np.zeros(total)
+    for f in range(nfr):
+        out[:, f * hop : f * hop + n_fft] += y[:, f]
+        env[f * hop : f * hop + n_fft] += wfull**2
+    s, e = n_fft // 2, total - n_fft // 2
+    return (out[:, s:e] / env[s:e]).astype(F32)
+
+
+def grn(x_btc, gamma, beta):
+    """GRN.forward (models/generator.py:496-499, models/conv_next.py:12-15): L2 over TIME (dim=1 of [B,T,C])."""
+    gx = np.sqrt((x_btc.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    nx = gx / (gx.mean(axis=-1, keepdims=True) + 1e-6)
+    return (gamma * (x_btc * nx) + beta + x_btc).astype(F32)
+
+
+def convnext_block(x, s, w: W, p: str, k: int):
+    """ConvNeXtBlock.forward (models/generator.py:468-485)."""
+    h = conv1d(x, w[p + "dwconv.weight"], w[p + "dwconv.bias"], padding=(k - 1) // 2, groups=x.shape[1])
+    h = adaptive_layer_norm(h.transpose(0, 2, 1), s, w, p + "norm", eps=1e-6)
+    h = silu(linear(h, w[p + "pwconv1.weight"], w[p + "pwconv1.bias"]))
+    h = grn(h, w[p + "grn.gamma"], w[p + "grn.beta"])
+    h = linear(h, w[p + "pwconv2.weight"], w[p + "pwconv2.bias"])
+    return (x + h.transpose(0, 2, 1)).astype(F32)
+
+
+def align_branch(phase, hint):
+    """Resolve atan2 branch-cut ties the way another run did.
+
+    ``har_phase = atan2(Im, Re)`` (generator.py:408) sits ON the branch cut wherever Im ≈ 0 and Re < 0.
+    That is systematic for frame 0: with ``center=True`` reflect padding the first STFT frame is
+    even-symmetric about its centre, so its spectrum is real up to FFT rounding and every bin with a
+    negative real part comes out as +π or −π by the sign of rounding noise (in the reference too —
+    torch's own FFT decides).  Elsewhere it happens at isolated bins.  Both signs are correct roundings of
+    the same value, but the ±2π jump feeds ``phase_prior_conv`` linearly, so two implementations can only be
+    compared after choosing the same branch.  hint = (flat_idx, sign) recorded from a run, or a full
+    reference array of the same shape; only values within 4e-3 of ±π are touched."""
+    if hint is None:
+        return phase
+    phase = phase.copy()
+    if isinstance(hint, tuple):
+        idx, sign = hint
+        flat = phase.reshape(-1)
+        near = np.abs(np.abs(flat[idx]) - np.pi) < 4e-3
+        flat[idx[near]] = (sign[near] * np.abs(flat[idx[near]])).astype(F32)
+        return flat.reshape(phase.shape)
+    d = phase.astype(np.float64) - hint
+    flip = (np.abs(np.abs(d) - 2 * np.pi) < 8e-3) & (np.abs(np.abs(hint) - np.pi) < 4e-3)
+    phase[flip] = -phase[flip]
+    return phase
+
+
+def generator_forward(mel, style, pitch, src_noise, init_phase, w: W, p: str = "generator.", cfg=None, return_intermediates=False, branch_hint=None):
+    """Generator.forward (models/generator.py:402-438) with the two RNG draws explicit.  `energy` is
+    accepted by the reference but unused.  Returns audio [B,1,75*T4], logamp, phase [B,1025,T4+1].
+    branch_hint: see align_branch."""
+    n_fft, hop, win = 2048, 75, 1200
+    f0 = pitch[:, None, :]
+    prior = generate_pcph(f0, src_noise, init_phase, hop=hop)[:, 0, :]
+    har_spec, hx, hy = stft_transform(prior, n_fft, hop, win)
+    har_phase = np.arctan2(hy, hx).astype(F32)
+    har_spec, har_phase = har_spec[:, :, :-1], har_phase[:, :, :-1]
+    har_phase = align_branch(har_phase, branch_hint)
+    la_prior = conv1d(har_spec, w[p + "amp_prior_conv.weight"], w[p + "amp_prior_conv.bias"], padding=3)
+    ph_prior = conv1d(har_phase, w[p + "phase_prior_conv.weight"], w[p + "phase_prior_conv.bias"], padding=3)
+    x = conv1d(np.concatenate([mel, la_prior, ph_prior], axis=1), w[p + "projector.weight"], w[p + "projector.bias"])
+    for i, k in enumerate((31, 15, 7, 3)):
+        x = convnext_block(x, style, w, p + f"convnext.{i}.", k)
+    xt = x.transpose(0, 2, 1)
+    kk = w[p + "amp_output_conv.weight"].shape[2]
+    la = adaptive_layer_norm(xt, style, w, p + "amp_final_layer_norm").transpose(0, 2, 1)
+    la = conv1d(np.concatenate([la, la_prior], axis=1), w[p + "amp_output_conv.weight"], w[p + "amp_output_conv.bias"], padding=(kk - 1) // 2)
+    ph = adaptive_layer_norm(xt, style, w, p + "phase_final_layer_norm").transpose(0, 2, 1)
+    ph = conv1d(np.concatenate([ph, ph_prior], axis=1), w[p + "phase_output_conv.weight"], w[p + "phase_output_conv.bias"], padding=(kk - 1) // 2)
+    la = np.concatenate([la, la[:, :, -1:]], axis=2)  # F.pad replicate (generator.py:425-426)
+    ph = np.concatenate([ph, ph[:, :, -1:]], axis=2)
+    spec = np.exp(la)
+    audio = np.tanh(istft(spec, np.cos(ph), np.sin(ph), n_fft, hop, win))[:, None, :].astype(F32)
+    if return_intermediates:
+        return audio, la, ph, dict(prior_signal=prior, har_spec=har_spec, har_phase=har_phase)
+    return audio, la, ph
+
+
+# --------------------------------------------------------------------------------------
+# length regulator + SpeechPredictor composition (row 7)
+# --------------------------------------------------------------------------------------
+def upsample_linear4(x):
+    """nn.Upsample(scale_factor=4, mode='linear', align_corners=False) on [B, T] (speech_predictor.py:64,89-90)."""
+    B, T = x.shape
+    o = np.arange(4 * T)
+    src = np.maximum((o + 0.5) / 4.0 - 0.5, 0.0).astype(F32)
+    i0 = np.floor(src).astype(np.int64)
+    i1 = np.minimum(i0 + 1, T - 1)
+    lam = (src - i0).astype(F32)
+    return ((F32(1) - lam) * x[:, i0] + lam * x[:, i1]).astype(F32)
+
+
+def frame_path(asr, pitch4, energy4, style, noise, w: W, branch_hint=None):
+    """decoder → prior → reverse flow → post_flow → generator (speech_predictor.py:92-118)."""
+    x = decoder_forward(asr, pitch4, energy4, style, w)
+    z, _, _ = prior_encoder(x, noise["prior_noise"], w)
+    z2 = flow_reverse(z, style[:, :, None], w)
+    mel = post_flow(z2, w)
+    return generator_forward(mel, style, pitch4, noise["src_noise"], noise["init_phase"], w, branch_hint=branch_hint)
+
+
+def speech_predictor_forward(texts, lengths, alignment, pitch, energy, noise, w: W, cfg, branch_hint=None):
+    """SpeechPredictor.forward (models/speech_predictor.py:85-129), audio_gt=None."""
+    enc, _, _ = text_encoder(texts, lengths, sub(w, "text_encoder."), cfg)
+    style = text_style_encoder(enc, lengths, sub(w, "style_encoder."), cfg)
+    al4 = np.repeat(alignment, 4, axis=2)
+    p4, e4 = upsample_linear4(pitch), upsample_linear4(energy)
+    asr = np.matmul(enc, al4).astype(F32)
+    return frame_path(asr, p4, e4, style, noise, w, branch_hint)
+
+
+# --------------------------------------------------------------------------------------
+# phoneme-rate: TextEncoder, TextStyleEncoder, ProsodyEncoder, predictors (rows 1-6)
+# --------------------------------------------------------------------------------------
+def channel_layer_norm(x, gamma, beta, eps=1e-4):
+    """text_encoder.LayerNorm over channels of [B,C,T] (models/text_encoder.py:24-33)."""
+    x64 = x.astype(np.float64)
+    m = x64.mean(1, keepdims=True)
+    v = ((x64 - m) ** 2).mean(1, keepdims=True)
+    return (((x64 - m) / np.sqrt(v + eps)) * gamma[None, :, None] + beta[None, :, None]).astype(F32)
+
+
+def rope(x, d):
+    """RotaryPositionalEmbeddings.forward on [B,H,T,kc] rotating the first d features
+    (models/text_encoder.py:100-168)."""
+    T = x.shape[2]
+    theta = (1.0 / (10000.0 ** (np.arange(0, d, 2, dtype=F32) / F32(d)))).astype(F32)
+    ang = (np.arange(T, dtype=F32)[:, None] * theta[None, :]).astype(F32)
+    ang = np.concatenate([ang, ang], axis=1)
+    c, s = np.cos(ang).astype(F32)[None, None], np.sin(ang).astype(F32)[None, None]
+    xr, xp = x[..., :d], x[..., d:]
+    neg = np.concatenate([-xr[..., d // 2 :], xr[..., : d // 2]], axis=-1)
+    return np.concatenate([xr * c + neg * s, xp], axis=-1).astype(F32)
+
+
+def multi_head_attention(x, c, w: W, p: str, n_heads: int, mask_keep=None):
+    """MultiHeadAttention.forward (models/text_encoder.py:214-296).  mask_keep: boolean [B,1,Tq,Tk] or
+    broadcastable; scores get -1e4 where it is False (text_encoder.py:255-262)."""
+    q = conv1d(x, w[p + "conv_q.weight"], w[p + "conv_q.bias"])
+    k = conv1d(c, w[p + "conv_k.weight"], w[p + "conv_k.bias"])
+    v = conv1d(c, w[p + "conv_v.weight"], w[p + "conv_v.bias"])
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    kc = C // n_heads
+    heads = lambda a: a.reshape(B, n_heads, kc, a.shape[2]).transpose(0, 1, 3, 2)  # noqa: E731
+    d = int(kc * 0.5)
+    qh, kh, vh = rope(heads(q), d), rope(heads(k), d), heads(v)
+    scores = np.matmul(qh.astype(np.float64), kh.astype(np.float64).transpose(0, 1, 3, 2)) / math.sqrt(kc)
+    if mask_keep is not None:
+        scores = scores + np.where(mask_keep, 0.0, -1e4)
+    scores -= scores.max(-1, keepdims=True)
+    pa = np.exp(scores)
+    pa /= pa.sum(-1, keepdims=True)
+    out = np.matmul(pa, vh.astype(np.float64)).astype(F32)  # [B,H,Tq,kc]
+    out = out.transpose(0, 1, 3, 2).reshape(B, C, Tq)
+    return conv1d(out, w[p + "conv_o.weight"], w[p + "conv_o.bias"])
+
+
+def ffn(x, x_mask, w: W, p: str, k: int):
+    """FFN.forward (models/text_encoder.py:324-329)."""
+    h = conv1d(x * x_mask, w[p + "conv_1.weight"], w[p + "conv_1.bias"], padding=k // 2)
+    h = np.maximum(h, 0)
+    h = conv1d(h * x_mask, w[p + "conv_2.weight"], w[p + "conv_2.bias"], padding=k // 2)
+    return (h * x_mask).astype(F32)
+
+
+def text_encoder(texts, lengths, w: W, cfg):
+    """TextEncoder.forward (models/text_encoder.py:433-462) → (mu, x, x_mask)."""
+    te = cfg.text_encoder
+    C = te.hidden_dim
+    x = (w["emb.weight"][texts] * F32(math.sqrt(C))).transpose(0, 2, 1).astype(F32)
+    P = x.shape[2]
+    x_mask = sequence_mask(lengths, P)[:, None, :].astype(F32)
+    # ConvReluNorm prenet (text_encoder.py:79-86)
+    x_org = x
+    h = x
+    for i in range(3):
+        h = conv1d(h * x_mask, w[f"prenet.conv_layers.{i}.weight"], w[f"prenet.conv_layers.{i}.bias"], padding=2)
+        h = channel_layer_norm(h, w[f"prenet.norm_layers.{i}.gamma"], w[f"prenet.norm_layers.{i}.beta"])
+        h = np.maximum(h, 0)
+    x = ((x_org + conv1d(h, w["prenet.proj.weight"], w["prenet.proj.bias"])) * x_mask).astype(F32)
+    # Encoder (text_encoder.py:377-393)
+    keep = (x_mask[:, :, None, :] * x_mask[:, :, :, None]) > 0
+    for i in range(te.layers):
+        x = x * x_mask
+        y = multi_head_attention(x, x, w, f"encoder.attn_layers.{i}.", te.heads, keep)
+        x = channel_layer_norm(x + y, w[f"encoder.norm_layers_1.{i}.gamma"], w[f"encoder.norm_layers_1.{i}.beta"])
+        y = ffn(x, x_mask, w, f"encoder.ffn_layers.{i}.", te.kernel_size)
+        x = channel_layer_norm(x + y, w[f"encoder.norm_layers_2.{i}.gamma"], w[f"encoder.norm_layers_2.{i}.beta"])
+    x = (x * x_mask).astype(F32)
+    mu = (conv1d(x, w["proj_m.weight"], w["proj_m.bias"]) * x_mask).astype(F32)
+    return mu, x, x_mask
+
+
+def text_style_encoder(x, lengths, w: W, cfg):
+    """TextStyleEncoder.forward (models/text_style_encoder.py:20-26) with BasicConvNeXtBlock
+    (models/conv_next.py:38-51): statistics run over the PADDED axis, only the final mean is masked."""
+    h = conv1d(x, w["conv_in.weight"], w["conv_in.bias"], padding=3)
+    for i in range(cfg.style_encoder.layers):
+        q = f"blocks.{i}."
+        r = h
+        y = conv1d(h, w[q + "dwconv.weight"], w[q + "dwconv.bias"], padding=3, groups=h.shape[1]).transpose(0, 2, 1)
+        y = layer_norm_last(y, 1e-6) * w[q + "norm.weight"] + w[q + "norm.bias"]
+        y = gelu(linear(y.astype(F32), w[q + "pwconv1.weight"], w[q + "pwconv1.bias"]))
+        y = grn(y, w[q + "grn.gamma"], w[q + "grn.beta"])
+        y = linear(y, w[q + "pwconv2.weight"], w[q + "pwconv2.bias"]).transpose(0, 2, 1)
+        h = (r + y).astype(F32)
+    mask = sequence_mask(lengths, h.shape[2])[:, None, :].astype(F32)
+    return ((h * mask).sum(axis=2) / np.asarray(lengths, F32)[:, None]).astype(F32)
+
+
+def prosody_encoder(x, style, lengths, w: W, n_layers: int, n_heads: int = 2):
+    """ProsodyEncoder.forward (models/prosody_encoder.py:63-81) → [B, P, d_model+style]."""
+    B, _, P = x.shape
+    x_mask = sequence_mask(lengths, P)[:, None, :].astype(F32)
+    keep = (x_mask[:, :, None, :] * x_mask[:, :, :, None]) > 0
+    st = np.broadcast_to(style[:, :, None], (B, style.shape[1], P)).astype(F32)
+    x = np.concatenate([x, st], axis=1)
+    for i in range(n_layers):
+        x = x * x_mask
+        y = multi_head_attention(x, x, w, f"attn_layers.{i}.", n_heads, keep)
+        x = adaptive_layer_norm((x + y).transpose(0, 2, 1), style, w, f"norm_layers_1.{i}").transpose(0, 2, 1)
+        y = ffn(x, x_mask, w, f"ffn_layers.{i}.", 1)
+        x = adaptive_layer_norm((x + y).transpose(0, 2, 1), style, w, f"norm_layers_2.{i}").transpose(0, 2, 1)
+        x = conv1d(x, w[f"proj_layers.{i}.weight"], w[f"proj_layers.{i}.bias"])
+        x = np.concatenate([x, st], axis=1)
+    return (x * x_mask).transpose(0, 2, 1).astype(F32)
+
+
+def duration_predictor(texts, lengths, w: W, cfg, return_intermediates=False):
+    """DurationPredictor.forward (models/duration_predictor.py:30-36) → logits [B,P,16]."""
+    enc, xh, _ = text_encoder(texts, lengths, sub(w, "text_encoder."), cfg)
+    style = text_style_encoder(enc, lengths, sub(w, "style_encoder."), cfg)
+    pros = prosody_encoder(enc, style, lengths, sub(w, "prosody_encoder."), cfg.duration_predictor.n_layer)
+    logits = linear(pros, w["duration_proj.linear_layer.weight"], w["duration_proj.linear_layer.bias"])
+    if return_intermediates:
+        return logits, dict(text_mu=enc, text_x=xh, style=style, prosody=pros)
+    return logits
+
+
+def prediction_to_duration(pred):
+    """DurationProcessor.prediction_to_duration (train/utils.py:468-474): pred [P,16] → dur [P] (float)."""
+    p64 = pred.astype(np.float64)
+    e = np.exp(p64 - p64.max(-1, keepdims=True))
+    sm = (e / e.sum(-1, keepdims=True)).astype(F32)
+    soft = np.maximum(np.round((sm * CLASS_TO_DUR).sum(-1, dtype=F32)), 1.0)  # torch.round = half-to-even = np.round
+    hard = CLASS_TO_DUR[np.argmax(pred, axis=-1)]
+    return np.where(hard < 7, hard, soft).astype(F32)
+
+
+def duration_to_alignment(dur):
+    """DurationProcessor.duration_to_alignment (train/utils.py:476-489)."""
+    d = dur.astype(np.int32)
+    idx = np.repeat(np.arange(len(d)), d)
+    a = np.zeros((len(d), len(idx)), F32)
+    a[idx, np.arange(len(idx))] = 1
+    return a
+
+
+def build_band_keep(alignment, lengths, window=5):
+    """build_monotonic_band_mask (models/pitch_energy_predictor.py:194-212) as consumed by
+    MultiHeadAttention.attention: the function returns True where attention is NOT allowed, but the
+    attention fills -1e4 where its mask argument is FALSE (text_encoder.py:255-262).  Net effect,
+    reproduced here bug-for-bug: scores are suppressed INSIDE the ±window band (and on real tokens),
+    and left untouched outside the band and on padded keys.  Returns the boolean 'keep' array
+    [B,1,F,T] = the reference's full_mask."""
+    B, T, Fr = alignment.shape
+    tau = alignment.argmax(axis=1)  # [B,F]
+    t_idx = np.arange(T)[None, None, :]
+    band = (t_idx >= (tau[:, :, None] - window)) & (t_idx <= (tau[:, :, None] + window))
+    key_pad = (np.arange(T)[None, :] + 1 > np.asarray(lengths)[:, None])[:, None, :]  # length_to_mask, utils.py:59-67
+    return (~band | key_pad)[:, None]
+
+
+def pitch_energy_predictor(text_encoding, lengths, alignment, style, w: W, cfg, return_intermediates=False):
+    """PitchEnergyPredictor.forward (models/pitch_energy_predictor.py:104-121)."""
+    pros = prosody_encoder(text_encoding, style, lengths, sub(w, "prosody_encoder."), 3)  # [B,P,C]
+    # compute_cross (pitch_energy_predictor.py:83-102)
+    base = np.matmul(pros.transpose(0, 2, 1), alignment).astype(F32)  # [B,C,F]
+    query = adaptive_layer_norm(base.transpose(0, 2, 1), style, w, "query_norm").transpose(0, 2, 1)
+    key = adaptive_layer_norm(pros, style, w, "key_norm").transpose(0, 2, 1)
+    keep = build_band_keep(alignment, lengths, 5)
+    att = multi_head_attention(query, key, w, "cross_attention.", 8, keep)
+    C = att.shape[1]
+    att = conv1d(att, wn_param(w, "cross_post.0"), w["cross_post.0.bias"], padding=2, groups=C)
+    att = conv1d(silu(att), wn_param(w, "cross_post.2"), w["cross_post.2.bias"])
+    x = ((base + att) / F32(math.sqrt(2.0))).astype(F32)
+    f0 = x
+    for i in range(3):
+        f0 = adaptive_decoder_block(f0, style, w, f"F0.{i}")
+    f0 = conv1d(f0, w["F0_proj.weight"], w["F0_proj.bias"])[:, 0]
+    n = x
+    for i in range(3):
+        n = adaptive_decoder_block(n, style, w, f"N.{i}")
+    n = conv1d(n, w["N_proj.weight"], w["N_proj.bias"])[:, 0]
+    if return_intermediates:
+        return f0, n, dict(prosody=pros, cross=x)
+    return f0, n
+
+
+def export_model_forward(texts, lengths, alignment, noise, weights: Dict[str, W], cfg, branch_hint=None):
+    """ExportModel.forward (models/export_model.py:35-45): weights = {module name: state dict}."""
+    pe_enc, _, _ = text_encoder(texts, lengths, weights["pe_text_encoder"], cfg)
+    pe_style = text_style_encoder(pe_enc, lengths, weights["pe_text_style_encoder"], cfg)
+    pitch, energy = pitch_energy_predictor(pe_enc, lengths, alignment, pe_style, weights["pitch_energy_predictor"], cfg)
+    audio, _, _ = speech_predictor_forward(
+        texts, lengths, alignment, pitch, energy, noise, weights["speech_predictor"], cfg, branch_hint
+    )
+    return audio, pitch, energy

@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the REFERENCE in the build container.
+
+Runs only where ``/root/reference`` exists (never on the GPU box, never from tests).
+It imports the reference's own modules from ``/root/reference/src`` (three
+``sys.modules`` stubs for absent third-party packages the hot path never calls:
+``munch``, ``pynvml``, ``torchaudio`` — SURVEY.md §8c), loads the name-keyed
+synthetic weights of ``stylish_tts_amd.params`` into them, records the three RNG
+draws on the inference path (``models/flow.py:314``, ``models/generator.py:272,306``)
+and stores inputs + expected outputs as small ``.npz`` fixtures next to this
+script.  Nothing of the reference (source, bytecode, traced graphs) is written.
+
+    python tests/golden/gen_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF_SRC = "/root/reference/src"
+
+
+def _install_stubs():
+    m = types.ModuleType("munch")
+
+    class Munch(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    m.Munch = Munch
+    sys.modules["munch"] = m
+    p = types.ModuleType("pynvml")
+    for n in ("nvmlInit", "nvmlDeviceGetHandleByIndex", "nvmlDeviceGetMemoryInfo"):
+        setattr(p, n, lambda *a, **k: None)
+    sys.modules["pynvml"] = p
+    ta = types.ModuleType("torchaudio")
+    tam = types.ModuleType("torchaudio.models")
+    tat = types.ModuleType("torchaudio.transforms")
+    tam.Conformer = object
+    tat.Spectrogram = object
+    ta.models, ta.transforms = tam, tat
+    sys.modules.update({"torchaudio": ta, "torchaudio.models": tam, "torchaudio.transforms": tat})
+
+
+_install_stubs()
+sys.path.insert(0, REF_SRC)
+import torch  # noqa: E402
+
+from stylish_tts.lib.config_loader import load_model_config_yaml  # noqa: E402
+from stylish_tts.train.models.ada_norm import AdaptiveGeneratorBlock  # noqa: E402
+from stylish_tts.train.models.duration_predictor import DurationPredictor  # noqa: E402
+from stylish_tts.train.models.export_model import ExportModel  # noqa: E402
+from stylish_tts.train.models.pitch_energy_predictor import PitchEnergyPredictor  # noqa: E402
+from stylish_tts.train.models.speech_predictor import SpeechPredictor  # noqa: E402
+from stylish_tts.train.models.text_encoder import TextEncoder  # noqa: E402
+from stylish_tts.train.models.text_style_encoder import TextStyleEncoder  # noqa: E402
+from stylish_tts.train.utils import DurationProcessor  # noqa: E402
+
+from stylish_tts_amd import params, synth  # noqa: E402
+from stylish_tts_amd.config import load_model_config  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(1234)
+SEED = 0
+
+
+class Replay:
+    """Feed predetermined tensors to torch.randn / rand / randn_like inside the block.
+
+    The three draws on the inference path (flow.py:314 randn_like; generator.py:272 randn,
+    :306 rand) are replaced by hash-generated tensors that the tests regenerate from the
+    same names, so fixtures need not store them."""
+
+    def __init__(self, randn=None, rand=None, randn_like=None):
+        self.q = {"randn": list(randn or []), "rand": list(rand or []), "randn_like": list(randn_like or [])}
+
+    def __enter__(self):
+        self._orig = (torch.randn, torch.rand, torch.randn_like)
+
+        def feed(tag):
+            def inner(*a, **k):
+                assert self.q[tag], f"unexpected extra torch.{tag} draw"
+                return torch.from_numpy(np.ascontiguousarray(self.q[tag].pop(0)))
+
+            return inner
+
+        torch.randn, torch.rand, torch.randn_like = feed("randn"), feed("rand"), feed("randn_like")
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.rand, torch.randn_like = self._orig
+        if exc[0] is None:
+            assert not any(self.q.values()), "unused injected draws"
+
+
+class CutTape:
+    """Record where the reference's har_phase (the torch.atan2 at generator.py:408) lies on the ±π branch
+    cut, and with which sign: flat indices into [B, bins, T4] (after the last frame is dropped) + signs."""
+
+    def __enter__(self):
+        self._orig = torch.atan2
+        self.out = None
+
+        def inner(y, x):
+            self.out = self._orig(y, x)
+            return self.out
+
+        torch.atan2 = inner
+        return self
+
+    def __exit__(self, *exc):
+        torch.atan2 = self._orig
+
+    def hints(self):
+        ph = self.out[:, :, :-1].contiguous().numpy().reshape(-1)
+        idx = np.nonzero(np.abs(ph) > np.pi - 2e-3)[0].astype(np.int32)
+        return dict(cut_idx=idx, cut_sign=np.sign(ph[idx]).astype(np.int8))
+
+
+def load_synth(module, name, cfg):
+    spec = params.module_spec(name, cfg)
+    sd = params.synth_state_dict(spec, SEED, prefix=name + ".")
+    ref_sd = module.state_dict()
+    ref_keys = [k for k in ref_sd if not k.startswith("posterior_encoder.")]
+    assert ref_keys == list(sd.keys()), f"{name}: key/order mismatch vs reference"
+    for k, v in sd.items():
+        assert tuple(ref_sd[k].shape) == v.shape, (name, k, ref_sd[k].shape, v.shape)
+    missing, unexpected = module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert all(k.startswith("posterior_encoder.") for k in missing), missing
+    assert not unexpected
+    return module.eval()
+
+
+def t(x, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(x)) if dtype is None else torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    mc = load_model_config_yaml(open(os.path.join(REF_SRC, "stylish_tts/train/config/model.yml")))
+    cfg = load_model_config()
+    meta = dict(torch_version=torch.__version__, seed=SEED)
+
+    sp = load_synth(SpeechPredictor(mc), "speech_predictor", cfg)
+    dp = load_synth(
+        DurationPredictor(
+            style_dim=mc.style_dim,
+            inter_dim=mc.inter_dim,
+            text_config=mc.text_encoder,
+            style_config=mc.style_encoder,
+            duration_config=mc.duration_predictor,
+        ),
+        "duration_predictor",
+        cfg,
+    )
+    pe = load_synth(
+        PitchEnergyPredictor(
+            style_dim=mc.style_dim,
+            inter_dim=mc.pitch_energy_predictor.inter_dim,
+            text_config=mc.text_encoder,
+            style_config=mc.style_encoder,
+            duration_config=mc.duration_predictor,
+            pitch_energy_config=mc.pitch_energy_predictor,
+        ),
+        "pitch_energy_predictor",
+        cfg,
+    )
+    pte = load_synth(TextEncoder(inter_dim=mc.pitch_energy_predictor.inter_dim, config=mc.text_encoder), "pe_text_encoder", cfg)
+    ptse = load_synth(
+        TextStyleEncoder(mc.pitch_energy_predictor.inter_dim, mc.style_dim, mc.style_encoder), "pe_text_style_encoder", cfg
+    )
+    durproc = DurationProcessor(mc.duration_predictor.duration_classes, mc.duration_predictor.max_duration)
+
+    # ---------------- frame-rate modules at a reduced shape (T4 = 64) ----------------
+    B, T4 = 1, 64
+    asr = t(synth.normal("g.asr", (B, 128, T4)))
+    pitch4 = t(synth.pitch_curve("g.pitch4", B, T4))
+    energy4 = t(synth.uniform("g.energy4", (B, T4)) * 2.0 + 2.0)
+    style = t(synth.normal("g.style", (B, 64)) * 0.7)
+    nz = synth.path_noise("frame64", B, T4)
+
+    print("decoder")
+    x_dec, _ = sp.decoder(asr, pitch4, energy4, style)
+    # one AdaIN res-block alone (row 9): the encode block on its concatenated input
+    F0c = sp.decoder.F0_conv(pitch4.unsqueeze(1))
+    Nc = sp.decoder.N_conv(energy4.unsqueeze(1))
+    enc_in = torch.cat([asr, F0c, Nc], dim=1)
+    enc_out = sp.decoder.encode(enc_in, style)
+    save("decoder", asr=asr, pitch=pitch4, energy=energy4, style=style, enc_in=enc_in, enc_out=enc_out, x=x_dec, **meta)
+
+    print("prior + reverse flow + post_flow")
+    with Replay(randn_like=[nz["prior_noise"]]):
+        z, mean, logstd = sp.prior_encoder(x_dec)
+    z2, _, _ = sp.flow(z, mean, logstd, 1, style.unsqueeze(-1), reverse=True)
+    mel = sp.post_flow(z2.mT).mT
+    save("flow", x=x_dec, style=style, z=z, z_out=z2, mel=mel, **meta)
+
+    print("generator")
+    with Replay(randn=[nz["src_noise"]], rand=[nz["init_phase"]]), CutTape() as cut:
+        pred = sp.generator(mel=mel, style=style, pitch=pitch4, energy=energy4)
+    cut_gen = cut.hints()
+    with Replay(randn=[nz["src_noise"]], rand=[nz["init_phase"]]):
+        p1 = pitch4.unsqueeze(1)
+        prior_sig = sp.generator.prior_generator(p1, (p1 > 10.0).float()).squeeze(1)
+    har_spec, hx, hy = sp.generator.stft.transform(prior_sig)
+    har_phase = torch.atan2(hy, hx)
+    save(
+        "generator",
+        mel=mel,
+        style=style,
+        pitch=pitch4,
+        energy=energy4,
+        prior_signal=prior_sig,
+        har_spec=har_spec[:, :, :-1],
+        har_phase=har_phase[:, :, :-1],
+        logamp=pred.magnitude,
+        phase=pred.phase,
+        audio=pred.audio,
+        **cut_gen,
+        **meta,
+    )
+
+    # pcph edge cases (row 13): all unvoiced; min f0 just above 20 Hz; K < 16 (every f0 > 750 Hz);
+    # transition frames in (10, 20] Hz (voiced but excluded from the min); a batch of two whose
+    # shared harmonic count comes from the other utterance
+    print("pcph edge cases")
+    edge = {}
+    Te = 24
+    ar = np.arange(Te)
+    cases = {
+        "unvoiced": np.zeros((1, Te), np.float32),
+        "low": np.where(ar % 5 == 0, 0.0, 20.5 + ar * 0.25).astype(np.float32)[None],
+        "high": np.where(ar < 4, 0.0, 800.0 + 10.0 * ar).astype(np.float32)[None],
+        "transition": np.concatenate([np.zeros(6), [12.0, 15.0, 18.0], 120 + np.arange(Te - 9) * 3.0]).astype(np.float32)[None],
+        "batch2": np.stack([np.full(Te, 900.0), np.where(ar < 8, 0.0, 140.0)]).astype(np.float32),
+    }
+    for nm, f0 in cases.items():
+        f0t = t(f0).unsqueeze(1)
+        nze = synth.path_noise("pcph." + nm, f0.shape[0], Te)
+        rand = [] if nm == "unvoiced" else [nze["init_phase"]]  # early return draws no phase (generator.py:275-276)
+        with Replay(randn=[nze["src_noise"]], rand=rand):
+            sig = sp.generator.prior_generator(f0t, (f0t > 10.0).float())
+        edge[f"{nm}_f0"] = f0
+        edge[f"{nm}_out"] = sig.numpy()
+    save("pcph_edges", **edge, **meta)
+
+    # ---------------- phoneme-rate modules ----------------
+    print("text encoder / style encoder / duration")
+    P = 12
+    texts = synth.tokens("g.texts", 1, P, mc.text_encoder.tokens)
+    lengths = np.array([P], np.int64)
+    mu, xenc, xmask = dp.text_encoder(t(texts), t(lengths))
+    sty = dp.style_encoder(mu, t(lengths))
+    pros = dp.prosody_encoder(mu, sty, t(lengths))
+    logits = dp(t(texts), t(lengths))
+    dur = durproc.prediction_to_duration(logits[0], P)
+    align = durproc(logits[0], P)
+    save(
+        "duration",
+        texts=texts,
+        lengths=lengths,
+        text_mu=mu,
+        text_x=xenc,
+        style=sty,
+        prosody=pros,
+        logits=logits,
+        duration=dur,
+        alignment_shape=np.array(align.shape),
+        **meta,
+    )
+    # B=2 ragged lengths through the text encoder + duration predictor (masking behaviour)
+    texts2 = synth.tokens("g.texts2", 2, P, mc.text_encoder.tokens)
+    len2 = np.array([P, 7], np.int64)
+    texts2[1, 6] = 0
+    texts2[1, 7:] = 0
+    logits2 = dp(t(texts2), t(len2))
+    mu2, _, _ = dp.text_encoder(t(texts2), t(len2))
+    sty2 = dp.style_encoder(mu2, t(len2))
+    save("duration_b2", texts=texts2, lengths=len2, text_mu=mu2, style=sty2, logits=logits2, **meta)
+
+    # duration processor alone, both branches of prediction_to_duration (utils.py:472)
+    lg = synth.normal("g.durlogits", (40, 16)) * 3.0
+    d_ = durproc.prediction_to_duration(t(lg), 40)
+    save("duration_processor", logits=lg, duration=d_, **meta)
+
+    print("pitch/energy predictor")
+    durs = synth.durations_for("g.durs", P, 40)
+    T = int(durs.sum())
+    align_m = synth.alignment_from_durations(durs)[None]
+    pe_enc, _, _ = pte(t(texts), t(lengths))
+    pe_sty = ptse(pe_enc, t(lengths))
+    pe_pros = pe.prosody_encoder(pe_enc, pe_sty, t(lengths))
+    from stylish_tts.train.utils import length_to_mask
+
+    pe_cross = pe.compute_cross(pe_pros, t(align_m), pe_sty, length_to_mask(t(lengths), P))
+    f0_pred, n_pred = pe(pe_enc, t(lengths), t(align_m), pe_sty)
+    save(
+        "pitch_energy",
+        texts=texts,
+        lengths=lengths,
+        durations=durs,
+        pe_text=pe_enc,
+        pe_style=pe_sty,
+        prosody=pe_pros,
+        cross=pe_cross,
+        f0=f0_pred,
+        energy=n_pred,
+        **meta,
+    )
+
+    print("speech predictor (tokens → audio), B=1 and B=2")
+    pitchT = synth.pitch_curve("g.pitchT", 1, T)
+    energyT = (synth.uniform("g.energyT", (1, T)) * 2.0 + 2.0).astype(np.float32)
+    nzs = synth.path_noise("sp1", 1, 4 * T)
+    with Replay(randn=[nzs["src_noise"]], rand=[nzs["init_phase"]], randn_like=[nzs["prior_noise"]]), CutTape() as cut:
+        pred = sp(t(texts), t(lengths), t(align_m), t(pitchT), t(energyT))
+    save("speech_predictor", texts=texts, lengths=lengths, durations=durs, pitch=pitchT, energy=energyT, audio=pred.audio, **cut.hints(), **meta)
+
+    texts_b = np.concatenate([texts, synth.tokens("g.texts_b", 1, P, mc.text_encoder.tokens)])
+    len_b = np.array([P, P], np.int64)
+    durs_b = np.stack([durs, durs[::-1]])
+    align_b = np.stack([synth.alignment_from_durations(d) for d in durs_b])
+    pitch_b = np.concatenate([pitchT, synth.pitch_curve("g.pitchT2", 1, T)])
+    energy_b = np.concatenate([energyT, energyT[:, ::-1].copy()])
+    nzb = synth.path_noise("sp2", 2, 4 * T)
+    with Replay(randn=[nzb["src_noise"]], rand=[nzb["init_phase"]], randn_like=[nzb["prior_noise"]]), CutTape() as cut:
+        pred = sp(t(texts_b), t(len_b), t(align_b), t(pitch_b), t(energy_b))
+    save("speech_predictor_b2", texts=texts_b, lengths=len_b, durations=durs_b, pitch=pitch_b, energy=energy_b, audio=pred.audio, **cut.hints(), **meta)
+
+    print("export model end to end (duration → alignment → audio)")
+    em = ExportModel(
+        speech_predictor=sp,
+        duration_predictor=dp,
+        pitch_energy_predictor=pe,
+        pe_text_encoder=pte,
+        pe_text_style_encoder=ptse,
+        device="cpu",
+    )
+    alignment_e = durproc(logits[0], P).unsqueeze(0)
+    Te_ = alignment_e.shape[2]
+    pe_f0, pe_n = pe(pe_enc, t(lengths), alignment_e, pe_sty)
+    nze = synth.path_noise("export", 1, 4 * Te_)
+    with Replay(randn=[nze["src_noise"]], rand=[nze["init_phase"]], randn_like=[nze["prior_noise"]]), CutTape() as cut:
+        audio_e = em(t(texts), t(lengths), alignment_e)
+    save("export_model", texts=texts, lengths=lengths, duration=dur, pitch=pe_f0, energy=pe_n, audio=audio_e, **cut.hints(), **meta)
+
+    print("3 s utterance through decoder → flow → vocoder (audio only)")
+    T4b = 960
+    asr_b = t(synth.normal("g3.asr", (1, 128, T4b)))
+    pitch_3 = t(synth.pitch_curve("g3.pitch", 1, T4b))
+    energy_3 = t(synth.uniform("g3.energy", (1, T4b)) * 2.0 + 2.0)
+    style_3 = t(synth.normal("g3.style", (1, 64)) * 0.7)
+    nz3 = synth.path_noise("frame960", 1, T4b)
+    with Replay(randn=[nz3["src_noise"]], rand=[nz3["init_phase"]], randn_like=[nz3["prior_noise"]]), CutTape() as cut:
+        xd, _ = sp.decoder(asr_b, pitch_3, energy_3, style_3)
+        z, mean, logstd = sp.prior_encoder(xd)
+        z2, _, _ = sp.flow(z, mean, logstd, 1, style_3.unsqueeze(-1), reverse=True)
+        mel3 = sp.post_flow(z2.mT).mT
+        pred3 = sp.generator(mel=mel3, style=style_3, pitch=pitch_3, energy=energy_3)
+    save("frame_path_3s", audio=pred3.audio, mel_probe=mel3[:, ::64, ::16], x_probe=xd[:, ::64, ::16], **cut.hints(), **meta)
+
+    print("AdaptiveGeneratorBlock (MRF + Snake) standalone")
+    blk = AdaptiveGeneratorBlock(128, 7, (1, 3, 5), 64)
+    spec = params.adaptive_generator_block_spec("", 128, 7, 64)
+    sdm = params.synth_state_dict(spec, SEED, prefix="mrf.")
+    assert set(sdm) == set(blk.state_dict()), set(sdm) ^ set(blk.state_dict())
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in sdm.items()})
+    blk.eval()
+    xm = t(synth.normal("g.mrf_x", (1, 128, 96)))
+    ym = blk(xm, style)
+    save("mrf_block", x=xm, style=style, y=ym, **meta)
+
+
+if __name__ == "__main__":
+    main()
