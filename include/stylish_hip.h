@@ -1,0 +1,131 @@
+/* stylish_hip.h — C-ABI of the MI355X (gfx950) implementation of the Stylish-TTS inference hot path.
+ *
+ * The reference (Fannovel16/stylish-tts) is 100 % Python: it has no FFI, plugin or operator interface, only
+ * nn.Module.forward() signatures.  This library sits UNDERNEATH those modules: the Python
+ * shims in stylish_tts_amd/modules.py keep the reference's constructor arguments, forward() signatures and
+ * state_dict keys and call the entry points below through ctypes.  Each entry point names the reference
+ * function it replaces (paths relative to /root/reference/src/stylish_tts/).
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, int status (0 = ok; stts_last_error() gives the text).  Never throws.
+ *  - `stream` is a hipStream_t passed as void*.  All work is enqueued on it; nothing synchronises unless stated.
+ *  - device tensors are fp32, TIME-MAJOR packed rows: X[utterance offset + frame][channel], row stride `ld`
+ *    floats (a multiple of 4).  Utterances are described by seg_off[n_utt + 1] (int32 row offsets), passed both
+ *    as a host array (grid sizing) and as a device array (kernels).
+ *  - the caller owns inputs, outputs and the workspace; the library owns the context and the packed weights.
+ *  - noise is an explicit input (the reference draws it from the global torch generator:
+ *    models/flow.py:314, models/generator.py:272,306).
+ */
+#ifndef STYLISH_HIP_H_
+#define STYLISH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct stts_ctx stts_ctx;
+
+/* Model shape: the hot-path keys of ModelConfig (lib/config_loader.py:369-414, train/config/model.yml). */
+typedef struct stts_model_dims {
+  int32_t n_fft, win_length, hop_length, sample_rate; /* 2048, 1200, 300, 24000 (vocoder hop = hop_length/4) */
+  int32_t style_dim, inter_dim;                      /* 64, 128 */
+  int32_t dec_hidden, dec_residual;                  /* decoder.hidden_dim 512, residual_dim 64 */
+  int32_t gen_input, gen_hidden, gen_inter, gen_io_kernel; /* generator.* : 512, 512, 1536, 7 */
+  int32_t tokens, te_hidden, te_filter, te_heads, te_layers, te_kernel; /* text_encoder.* */
+  int32_t style_layers;                              /* style_encoder.layers */
+  int32_t dur_layers, dur_classes, dur_max;          /* duration_predictor.n_layer, duration_classes, max_duration */
+  int32_t pe_inter;                                  /* pitch_energy_predictor.inter_dim */
+} stts_model_dims;
+
+const char* stts_last_error(void);
+int stts_version(void);
+
+/* Context: device selection + weights.  Weight tensors are handed over by their reference state_dict name,
+ * prefixed with the module name used by build_model (models/models.py:79-101), e.g.
+ * "speech_predictor.decoder.encode.conv1.parametrizations.weight.original1".  Data is copied (host fp32). */
+int stts_ctx_create(const stts_model_dims* dims, int device, stts_ctx** out);
+void stts_ctx_destroy(stts_ctx* ctx);
+int stts_load_weight(stts_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Fold weight-norm (w = g*v/||v||), re-lay out every conv/linear as W[cout][tap][cin] padded for the MFMA
+ * tiles, upload.  which: bit 0 frame-rate path (speech_predictor.{decoder,prior_encoder,flow,post_flow,generator}),
+ * bit 1 phoneme-rate predictors (text encoders, style encoders, duration, pitch/energy). */
+int stts_finalize_weights(stts_ctx* ctx, int which);
+/* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz
+ * (the reference raises there, models/generator.py:285).  Synchronises the stream. */
+int stts_check_status(stts_ctx* ctx, void* stream);
+
+/* Workspace the frame-rate stages need for `rows` vocoder frames (sum of T4) in `n_utt` utterances,
+ * the longest having `max_len` frames. */
+size_t stts_frame_workspace_bytes(const stts_ctx* ctx, int64_t rows, int n_utt, int max_len);
+
+/* Decoder.forward (models/decoder.py:47-60) incl. every AdaptiveDecoderBlock (models/ada_norm.py:166-182).
+ * asr [rows, ld_asr>=128], pitch/energy [rows] (already at the hop/4 rate), style [n_utt, 64] -> x [rows, 512]. */
+int stts_decoder_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                         const float* asr, int ld_asr, const float* pitch, const float* energy, const float* style,
+                         float* x_out, int ld_x, void* ws, size_t ws_bytes);
+
+/* PriorEncoder.forward (models/flow.py:311-315) + ResidualCouplingBlock.forward(reverse=True)
+ * (models/flow.py:132-151) + post_flow (models/speech_predictor.py:111).
+ * x [rows,512], prior_noise [rows,128] ~ N(0,1) -> mel [rows,512]; optional z_prior / z_flow [rows,128]. */
+int stts_prior_flow_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                            const float* x, int ld_x, const float* style, const float* prior_noise, float* mel_out, int ld_mel,
+                            float* z_prior_out, float* z_flow_out, void* ws, size_t ws_bytes);
+
+/* generate_pcph (models/generator.py:247-315) + TorchSTFT.transform + atan2 (models/generator.py:32-44,406-410).
+ * pitch [rows], src_noise [75*rows] ~ N(0,1), init_phase: device pointer to ONE float in [0,1) shared by the call.
+ * batch_scope != 0: harmonic count from the min f0 of the whole call (reference semantics of a batched call);
+ * 0: per utterance (the reference called per utterance).  Outputs har_spec / har_phase [rows, ld>=1025],
+ * optional prior_signal [75*rows]. */
+int stts_harmonic_stft(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                       const float* pitch, const float* src_noise, const float* init_phase, int batch_scope,
+                       float* prior_signal_out, float* har_spec, float* har_phase, int ld_har, void* ws, size_t ws_bytes);
+
+/* Generator.forward body + TorchSTFT.inverse + tanh (models/generator.py:412-433, ConvNeXtBlock :468-485,
+ * GRN :496-499, AdaptiveLayerNorm models/ada_norm.py:193-201).
+ * mel [rows,512], style [n_utt,64], har_spec/har_phase [rows, ld_har] -> audio [75*rows];
+ * optional logamp / phase [rows, ld_lp>=1025] (row T4 of the reference's replicate pad equals row T4-1). */
+int stts_vocoder_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                         const float* mel, int ld_mel, const float* style, const float* har_spec, const float* har_phase, int ld_har,
+                         float* audio_out, float* logamp_out, float* phase_out, int ld_lp, void* ws, size_t ws_bytes);
+
+/* The frame-rate hot path in one call: decoder -> prior -> reverse flow -> post_flow -> harmonic source ->
+ * STFT -> vocoder -> iSTFT (models/speech_predictor.py:92-118).  This is the benchmarked unit. */
+int stts_frame_path(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                    const float* asr, int ld_asr, const float* pitch, const float* energy, const float* style,
+                    const float* prior_noise, const float* src_noise, const float* init_phase, int batch_scope,
+                    float* audio_out, void* ws, size_t ws_bytes);
+
+/* Length regulator (train/utils.py:476-489 + models/speech_predictor.py:88-93): integer durations per token ->
+ * time-major gather of the phoneme encoding at rate rep (1: mel frames, 4: vocoder frames).
+ * dur [n_tok] int32 (device), tok_off [n_utt+1], frm_off [n_utt+1] (= rep * cumulative durations), both device.
+ * enc [n_tok, ld_enc] -> out [frames, ld_out] columns [0, C). */
+int stts_length_regulate(stts_ctx* ctx, void* stream, int n_utt, const int32_t* dur, const int32_t* tok_off, const int32_t* frm_off,
+                         int64_t n_frames, int rep, const float* enc, int ld_enc, int C, float* out, int ld_out, int32_t* src_row_ws);
+/* nn.Upsample(scale_factor=4, mode="linear") of pitch / energy (models/speech_predictor.py:64,89-90). */
+int stts_upsample4(stts_ctx* ctx, void* stream, int n_utt, const int32_t* off_T_host, const int32_t* off_T, const int32_t* off_T4,
+                   const float* x, float* y);
+
+/* Layout bridge for the nn.Module shims: reference [B, C, T] (equal T) <-> time-major rows. */
+int stts_to_time_major(void* stream, const float* x_bct, int B, int C, int T, float* y, int ldy);
+int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, int T, float* y_bct);
+
+/* Single operators, exposed for parity tests (same kernels the stages use). */
+/* F.conv1d(stride 1, zero pad (k-1)/2*dil) on time-major rows; w is the reference layout [cout, cin, k] on the HOST. */
+int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,
+                   const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile);
+/* AdaptiveDecoderBlock.forward (models/ada_norm.py:166-182) with weights named `prefix` + reference keys. */
+int stts_op_adain_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host,
+                        const int32_t* seg_off_dev, const float* x, int ldx, int cin, int cout, const float* style, float* y, int ldy,
+                        void* ws, size_t ws_bytes);
+/* AdaptiveGeneratorBlock.forward (HiFi-GAN MRF + Snake, models/ada_norm.py:109-120); standalone block only. */
+int stts_op_mrf_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host,
+                      const int32_t* seg_off_dev, const float* x, int ldx, int channels, int kernel, const float* style, float* y,
+                      int ldy, void* ws, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STYLISH_HIP_H_ */

@@ -328,30 +328,43 @@ def convnext_block(x, s, w: W, p: str, k: int):
     return (x + h.transpose(0, 2, 1)).astype(F32)
 
 
-def align_branch(phase, hint):
-    """Resolve atan2 branch-cut ties the way another run did.
+def circ_dist(a, b):
+    return np.abs(np.angle(np.exp(1j * (np.asarray(a, np.float64) - np.asarray(b, np.float64)))))
 
-    ``har_phase = atan2(Im, Re)`` (generator.py:408) sits ON the branch cut wherever Im ≈ 0 and Re < 0.
-    That is systematic for frame 0: with ``center=True`` reflect padding the first STFT frame is
-    even-symmetric about its centre, so its spectrum is real up to FFT rounding and every bin with a
-    negative real part comes out as +π or −π by the sign of rounding noise (in the reference too —
-    torch's own FFT decides).  Elsewhere it happens at isolated bins.  Both signs are correct roundings of
-    the same value, but the ±2π jump feeds ``phase_prior_conv`` linearly, so two implementations can only be
-    compared after choosing the same branch.  hint = (flat_idx, sign) recorded from a run, or a full
-    reference array of the same shape; only values within 4e-3 of ±π are touched."""
+
+def align_branch(phase, hint, spec=None, return_bad=False):
+    """Adopt another run's har_phase where atan2 is ill-conditioned.
+
+    ``har_phase = atan2(Im, Re)`` (generator.py:408) is discontinuous: (a) ON the branch cut (Im ~ 0, Re < 0) the
+    result is +pi or -pi by the sign of FFT rounding noise.  That is systematic for frame 0: with ``center=True``
+    reflect padding the first STFT frame is even-symmetric about its centre, so its spectrum is real up to rounding
+    and every negative-real bin flips a coin (in the reference too - torch's own FFT decides); elsewhere it happens
+    at isolated bins.  (b) Where the magnitude is ~0 the phase is pure rounding noise.  Either way both values are
+    legitimate roundings of the same quantity, but the jump feeds ``phase_prior_conv`` linearly, so two
+    implementations can only be compared after adopting the same values at those bins.
+
+    hint = (flat_idx, ref_phase) recorded from a run (tests/golden/gen_golden.py: CutTape), or a full reference
+    array of the same shape.  A value is only ever replaced when it is the same angle modulo 2*pi (circular
+    distance < 5e-3) or the bin is negligible (spec < 2e-4); anything else is left alone and counted as 'bad'."""
     if hint is None:
-        return phase
-    phase = phase.copy()
+        return (phase, 0) if return_bad else phase
+    phase = np.array(phase, dtype=F32, copy=True)
+    flat = phase.reshape(-1)
     if isinstance(hint, tuple):
-        idx, sign = hint
-        flat = phase.reshape(-1)
-        near = np.abs(np.abs(flat[idx]) - np.pi) < 4e-3
-        flat[idx[near]] = (sign[near] * np.abs(flat[idx[near]])).astype(F32)
-        return flat.reshape(phase.shape)
-    d = phase.astype(np.float64) - hint
-    flip = (np.abs(np.abs(d) - 2 * np.pi) < 8e-3) & (np.abs(np.abs(hint) - np.pi) < 4e-3)
-    phase[flip] = -phase[flip]
-    return phase
+        idx, ref = np.asarray(hint[0], np.int64), np.asarray(hint[1], F32)
+    else:
+        ref_full = np.asarray(hint, F32).reshape(-1)
+        d = np.abs(flat.astype(np.float64) - ref_full)
+        idx = np.nonzero(d > 1.0)[0]  # candidates: jumps of ~pi or ~2pi
+        ref = ref_full[idx]
+    ok = circ_dist(flat[idx], ref) < 5e-3
+    if spec is not None:
+        ok |= np.asarray(spec, F32).reshape(-1)[idx] < 2e-4
+    elif not isinstance(hint, tuple):
+        pass
+    flat[idx[ok]] = ref[ok]
+    out = flat.reshape(phase.shape)
+    return (out, int((~ok).sum())) if return_bad else out
 
 
 def generator_forward(mel, style, pitch, src_noise, init_phase, w: W, p: str = "generator.", cfg=None, return_intermediates=False, branch_hint=None):
@@ -364,7 +377,7 @@ def generator_forward(mel, style, pitch, src_noise, init_phase, w: W, p: str = "
     har_spec, hx, hy = stft_transform(prior, n_fft, hop, win)
     har_phase = np.arctan2(hy, hx).astype(F32)
     har_spec, har_phase = har_spec[:, :, :-1], har_phase[:, :, :-1]
-    har_phase = align_branch(har_phase, branch_hint)
+    har_phase = align_branch(har_phase, branch_hint, har_spec)
     la_prior = conv1d(har_spec, w[p + "amp_prior_conv.weight"], w[p + "amp_prior_conv.bias"], padding=3)
     ph_prior = conv1d(har_phase, w[p + "phase_prior_conv.weight"], w[p + "phase_prior_conv.bias"], padding=3)
     x = conv1d(np.concatenate([mel, la_prior, ph_prior], axis=1), w[p + "projector.weight"], w[p + "projector.bias"])

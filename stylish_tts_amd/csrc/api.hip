@@ -1,0 +1,321 @@
+// extern "C" entry points declared in include/stylish_hip.h.  Single translation unit: hipcc compiles this file
+// (which includes every kernel header) into libstylish_hip.so for gfx950.
+#include "model.hip.h"
+
+using namespace stts;
+
+#define API_BEGIN try {
+#define API_END                                                         \
+  }                                                                     \
+  catch (const std::exception& e) { return stts::fail("exception: %s", e.what()); } \
+  catch (...) { return stts::fail("unknown exception"); }
+
+extern "C" {
+
+const char* stts_last_error(void) { return stts::last_error().c_str(); }
+int stts_version(void) { return 1; }
+
+int stts_ctx_create(const stts_model_dims* dims, int device, stts_ctx** out) {
+  API_BEGIN
+  STTS_CHECK(dims && out, "null argument");
+  int n = 0;
+  STTS_HIP(hipGetDeviceCount(&n));
+  STTS_CHECK(device >= 0 && device < n, "device %d not available (%d visible)", device, n);
+  STTS_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  STTS_HIP(hipGetDeviceProperties(&prop, device));
+  STTS_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  stts_ctx* c = new stts_ctx();
+  c->d = *dims;
+  c->device = device;
+  void* p = nullptr;
+  STTS_HIP(hipMalloc(&p, 256));
+  STTS_HIP(hipMemset(p, 0, 256));
+  c->d_err = (int*)p;
+  c->allocs.push_back(p);
+  *out = c;
+  return 0;
+  API_END
+}
+
+void stts_ctx_destroy(stts_ctx* c) {
+  if (!c) return;
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+}
+
+int stts_load_weight(stts_ctx* c, const char* name, const float* data, const int64_t* shape, int ndim) {
+  API_BEGIN
+  STTS_CHECK(c && name && data && shape && ndim >= 1 && ndim <= 4, "bad argument");
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.shape.push_back(shape[i]);
+    n *= shape[i];
+  }
+  t.data.assign(data, data + n);
+  c->host[name] = std::move(t);
+  return 0;
+  API_END
+}
+
+int stts_finalize_weights(stts_ctx* c, int which) {
+  API_BEGIN
+  STTS_CHECK(c, "null ctx");
+  STTS_HIP(hipSetDevice(c->device));
+  if (which & 1) STTS_TRY(finalize_frame(c));
+  STTS_HIP(hipDeviceSynchronize());
+  return 0;
+  API_END
+}
+
+int stts_check_status(stts_ctx* c, void* stream) {
+  API_BEGIN
+  int e = 0;
+  STTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  STTS_HIP(hipMemcpy(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) {
+    STTS_HIP(hipMemset(c->d_err, 0, sizeof(int)));
+    return stts::fail("harmonic source: a frame is voiced (f0 > 10 Hz) but no f0 exceeds 20 Hz (reference raises: models/generator.py:285)");
+  }
+  return 0;
+  API_END
+}
+
+size_t stts_frame_workspace_bytes(const stts_ctx* c, int64_t rows, int n_utt, int max_len) { return frame_workspace_bytes(c, rows, n_utt, max_len); }
+
+#define SEG_CHECK()                                                                  \
+  STTS_CHECK(c && c->frame_ready, "frame-rate weights not finalized");               \
+  STTS_CHECK(n_utt > 0 && seg_off_host && seg_off_dev && seg_off_host[0] == 0, "bad utterance offsets"); \
+  for (int _u = 0; _u < n_utt; ++_u) STTS_CHECK(seg_off_host[_u + 1] > seg_off_host[_u], "utterance %d is empty", _u); \
+  Seg s{n_utt, seg_off_host, seg_off_dev};                                           \
+  hipStream_t st = (hipStream_t)stream
+
+int stts_decoder_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* asr,
+                         int ld_asr, const float* pitch, const float* energy, const float* style, float* x_out, int ld_x, void* ws,
+                         size_t ws_bytes) {
+  API_BEGIN
+  SEG_CHECK();
+  STTS_CHECK(ld_asr >= c->d.inter_dim && ld_asr % 4 == 0 && ld_x >= c->d.dec_hidden, "bad leading dimension");
+  Arena a(ws, ws_bytes);
+  return decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x_out, ld_x, a);
+  API_END
+}
+
+int stts_prior_flow_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x,
+                            int ld_x, const float* style, const float* prior_noise, float* mel_out, int ld_mel, float* z_prior_out,
+                            float* z_flow_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  SEG_CHECK();
+  STTS_CHECK(ld_x % 4 == 0 && ld_x >= c->d.dec_hidden && ld_mel >= c->d.dec_hidden, "bad leading dimension");
+  Arena a(ws, ws_bytes);
+  return prior_flow_forward(c, st, s, x, ld_x, style, prior_noise, mel_out, ld_mel, z_prior_out, z_flow_out, a);
+  API_END
+}
+
+int stts_harmonic_stft(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* pitch,
+                       const float* src_noise, const float* init_phase, int batch_scope, float* prior_signal_out, float* har_spec,
+                       float* har_phase, int ld_har, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  SEG_CHECK();
+  STTS_CHECK(ld_har >= kBins, "ld_har %d < %d", ld_har, kBins);
+  Arena a(ws, ws_bytes);
+  return harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, prior_signal_out, har_spec, har_phase, ld_har, a);
+  API_END
+}
+
+int stts_vocoder_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* mel,
+                         int ld_mel, const float* style, const float* har_spec, const float* har_phase, int ld_har, float* audio_out,
+                         float* logamp_out, float* phase_out, int ld_lp, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  SEG_CHECK();
+  STTS_CHECK(ld_mel % 4 == 0 && ld_har % 32 == 0 && ld_har >= round_up(kBins, 32), "har/mel leading dimension must cover 1056 columns, multiple of 32");
+  STTS_CHECK(!logamp_out || ld_lp >= kBins, "ld_lp too small");
+  Arena a(ws, ws_bytes);
+  return vocoder_forward(c, st, s, mel, ld_mel, style, har_spec, har_phase, ld_har, audio_out, logamp_out, phase_out, ld_lp, a);
+  API_END
+}
+
+int stts_frame_path(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* asr, int ld_asr,
+                    const float* pitch, const float* energy, const float* style, const float* prior_noise, const float* src_noise,
+                    const float* init_phase, int batch_scope, float* audio_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  SEG_CHECK();
+  STTS_CHECK(ld_asr >= c->d.inter_dim && ld_asr % 4 == 0, "bad ld_asr");
+  return frame_path(c, st, s, asr, ld_asr, pitch, energy, style, prior_noise, src_noise, init_phase, batch_scope, audio_out, ws, ws_bytes);
+  API_END
+}
+
+int stts_length_regulate(stts_ctx* c, void* stream, int n_utt, const int32_t* dur, const int32_t* tok_off, const int32_t* frm_off,
+                         int64_t n_frames, int rep, const float* enc, int ld_enc, int C, float* out, int ld_out, int32_t* src_row_ws) {
+  API_BEGIN
+  (void)c;
+  hipStream_t st = (hipStream_t)stream;
+  STTS_CHECK(C % 4 == 0 && ld_enc % 4 == 0 && ld_out % 4 == 0, "length_regulate: channel counts must be multiples of 4");
+  hipLaunchKernelGGL(frame_token_map_kernel, dim3(n_utt), dim3(256), 0, st, dur, tok_off, frm_off, rep, src_row_ws);
+  const long work = n_frames * (C / 4);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long>(2048, std::max<long>(1, (work + 255) / 256))), dim3(256), 0, st, enc, ld_enc,
+                     src_row_ws, out, ld_out, 0, C, (int)n_frames);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+int stts_upsample4(stts_ctx* c, void* stream, int n_utt, const int32_t* off_T_host, const int32_t* off_T, const int32_t* off_T4, const float* x,
+                   float* y) {
+  API_BEGIN
+  (void)c;
+  int ml = 0;
+  for (int u = 0; u < n_utt; ++u) ml = std::max(ml, off_T_host[u + 1] - off_T_host[u]);
+  hipLaunchKernelGGL(upsample4_kernel, dim3(ceil_div(4 * ml, 256), n_utt), dim3(256), 0, (hipStream_t)stream, x, off_T, off_T4, y);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+int stts_to_time_major(void* stream, const float* x, int B, int C, int T, float* y, int ldy) {
+  API_BEGIN
+  STTS_CHECK(ldy >= C, "ldy < C");
+  hipLaunchKernelGGL(to_time_major_kernel, dim3(ceil_div(T, 32), ceil_div(ldy, 32), B), dim3(256), 0, (hipStream_t)stream, x, B, C, T, y, ldy, 0, ldy);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, int T, float* y) {
+  API_BEGIN
+  hipLaunchKernelGGL(to_channel_major_kernel, dim3(ceil_div(T, 32), ceil_div(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, 0, B, C, T, y);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+// ------------------------------------------------------------------------------------------------ test operators
+int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,
+                   const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile) {
+  API_BEGIN
+  hipStream_t st = (hipStream_t)stream;
+  STTS_CHECK(ldx % 32 == 0 && ldx >= cin, "op_conv1d: ldx must be a multiple of 32 covering cin");
+  stts_ctx tmp;  // only for allocation bookkeeping
+  HostTensor w;
+  w.shape = {cout, cin, k};
+  w.data.assign(w_host, w_host + (size_t)cout * cin * k);
+  HostTensor b;
+  b.shape = {cout};
+  if (bias_host) b.data.assign(bias_host, bias_host + cout);
+  PackedConv pc;
+  STTS_TRY(pack_rows(&tmp, w, bias_host ? &b : nullptr, plain_rows(cout), 0, cin, round_up(cin, 32), cout, &pc));
+  Seg s{n_utt, seg_off_host, seg_off_dev};
+  GemmArgs a = gemm_args(s);
+  set_seg(a, 0, x, ldx, 0, pc, (k - 1) / 2, dil);
+  a.N = cout; a.bias = pc.bias; a.Y = y; a.ldy = ldy; a.act = act;
+  int r = launch_conv_gemm(st, a, EPI_STORE, pc.npad, n_utt, s.max_len(), force_tile);
+  hipError_t e = hipStreamSynchronize(st);
+  for (void* p : tmp.allocs) (void)hipFree(p);
+  STTS_HIP(e);
+  return r;
+  API_END
+}
+
+static int op_scratch(Arena& a, long R, int kc, int cout, int n_utt, float** act1, float** h, float** act2, float** ss, float** sty, int ld_sty) {
+  *act1 = a.get<float>(R * kc);
+  *h = a.get<float>(R * cout);
+  *act2 = a.get<float>(R * cout);
+  *ss = a.get<float>((size_t)n_utt * 2 * std::max(kc, cout));
+  *sty = a.get<float>((size_t)n_utt * ld_sty);
+  STTS_CHECK(a.ok, "op: workspace too small");
+  return 0;
+}
+
+int stts_op_adain_block(stts_ctx* c, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                        const float* x, int ldx, int cin, int cout, const float* style, float* y, int ldy, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  STTS_CHECK(c && prefix, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::string key = prefix;
+  if (!c->op_blocks.count(key)) {
+    auto blk = std::make_unique<AdainBlockW>();
+    auto tab = std::make_unique<StyleTable>();
+    STTS_TRY(pack_adain_block(c, key, cin, cout, tab.get(), blk.get()));
+    STTS_TRY(upload_table(c, tab.get()));
+    c->op_blocks[key] = std::move(blk);
+    c->op_tables[key] = std::move(tab);
+  }
+  const AdainBlockW& B = *c->op_blocks[key];
+  const StyleTable& T = *c->op_tables[key];
+  STTS_CHECK(ldx == B.kcin, "op_adain_block: ldx must equal cin padded to 32 (%d)", B.kcin);
+  Seg s{n_utt, seg_off_host, seg_off_dev};
+  Arena a(ws, ws_bytes);
+  float *act1, *h, *act2, *ss, *sty;
+  STTS_TRY(op_scratch(a, s.rows(), B.kcin, B.cout, n_utt, &act1, &h, &act2, &ss, &sty, T.ld()));
+  STTS_TRY(run_style(st, T, style, n_utt, sty));
+  return run_adain_block(st, s, B, sty, T.ld(), x, ldx, y, ldy, act1, h, act2, ss);
+  API_END
+}
+
+int stts_op_mrf_block(stts_ctx* c, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
+                      const float* x, int ldx, int channels, int kernel, const float* style, float* y, int ldy, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  STTS_CHECK(c && prefix, "null argument");
+  STTS_CHECK(channels % 32 == 0 && ldx == channels && ldy == channels, "op_mrf_block: channels must be a multiple of 32 and ld == channels");
+  hipStream_t st = (hipStream_t)stream;
+  std::string key = prefix;
+  if (!c->op_mrf.count(key)) {
+    auto m = std::make_unique<MrfW>();
+    m->channels = channels;
+    m->kernel = kernel;
+    for (int i = 0; i < 3; ++i) {
+      const std::string si = std::to_string(i);
+      STTS_TRY(pack_plain(c, key + "convs1." + si, true, 0, channels, &m->c1[i]));
+      STTS_TRY(pack_plain(c, key + "convs2." + si, true, 0, channels, &m->c2[i]));
+      STTS_TRY(add_style(c, &m->table, key + "adain1." + si, channels, &m->a1[i]));
+      STTS_TRY(add_style(c, &m->table, key + "adain2." + si, channels, &m->a2[i]));
+      STTS_GET(al1, key + "alpha1." + si);
+      STTS_GET(al2, key + "alpha2." + si);
+      STTS_TRY(dev_upload(c, al1->data, &m->alpha1[i]));
+      STTS_TRY(dev_upload(c, al2->data, &m->alpha2[i]));
+    }
+    STTS_TRY(upload_table(c, &m->table));
+    c->op_mrf[key] = std::move(m);
+  }
+  const MrfW& M = *c->op_mrf[key];
+  Seg s{n_utt, seg_off_host, seg_off_dev};
+  const long R = s.rows();
+  Arena a(ws, ws_bytes);
+  float* cur = a.get<float>(R * channels);
+  float* t1 = a.get<float>(R * channels);
+  float* t2 = a.get<float>(R * channels);
+  float* ss = a.get<float>((size_t)n_utt * 2 * channels);
+  float* sty = a.get<float>((size_t)n_utt * M.table.ld());
+  STTS_CHECK(a.ok, "op_mrf_block: workspace too small");
+  STTS_TRY(run_style(st, M.table, style, n_utt, sty));
+  STTS_HIP(hipMemcpyAsync(cur, x, R * channels * sizeof(float), hipMemcpyDeviceToDevice, st));
+  const int ml = s.max_len(), lds = M.table.ld();
+  // 3 x { AdaIN -> Snake -> dilated conv -> AdaIN -> Snake -> conv -> + x }  (models/ada_norm.py:109-120)
+  for (int i = 0; i < 3; ++i) {
+    hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(channels, 32), n_utt), dim3(256), 0, st, cur, channels, channels, s.dev, sty, lds,
+                       M.a1[i].col0, 1e-5f, ss, 2 * channels);
+    hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, channels / 4), dim3(256), 0, st, cur, channels, t1, channels, channels, s.dev, ss,
+                       2 * channels, (int)ACT_NONE, (const float*)M.alpha1[i]);
+    GemmArgs g1 = gemm_args(s);
+    set_seg(g1, 0, t1, channels, 0, M.c1[i], (kernel - 1) / 2, M.dil[i]);
+    g1.N = channels; g1.bias = M.c1[i].bias; g1.Y = t2; g1.ldy = channels;
+    STTS_TRY(launch_conv_gemm(st, g1, EPI_STORE, M.c1[i].npad, n_utt, ml));
+    hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(channels, 32), n_utt), dim3(256), 0, st, t2, channels, channels, s.dev, sty, lds,
+                       M.a2[i].col0, 1e-5f, ss, 2 * channels);
+    hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, channels / 4), dim3(256), 0, st, t2, channels, t1, channels, channels, s.dev, ss,
+                       2 * channels, (int)ACT_NONE, (const float*)M.alpha2[i]);
+    GemmArgs g2 = gemm_args(s);
+    set_seg(g2, 0, t1, channels, 0, M.c2[i]);
+    g2.N = channels; g2.bias = M.c2[i].bias; g2.R = cur; g2.ldr = channels;
+    float* dst = i == 2 ? y : t2;
+    g2.Y = dst; g2.ldy = channels;
+    STTS_TRY(launch_conv_gemm(st, g2, EPI_STORE, M.c2[i].npad, n_utt, ml));
+    if (i < 2) std::swap(cur, t2);
+  }
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+}  // extern "C"

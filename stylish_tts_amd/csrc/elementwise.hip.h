@@ -1,0 +1,419 @@
+// HBM-bound kernels of the frame-rate path: style projections, instance-norm statistics and AdaIN apply,
+// row LayerNorm / AdaLN, depthwise conv, GRN finalisation, length regulator, layout transposes.
+// All activations are time-major packed rows (see gemm.hip.h); every kernel reads/writes float4 along the
+// channel axis so a wave touches 1 KiB contiguous per instruction.
+#pragma once
+#include "common.h"
+#include "gemm.hip.h"
+
+namespace stts {
+
+// ---------------------------------------------------------------------------------------------
+// style projections: out[u][j] = b[j] + sum_k W[j][k] * s[u][k]   (K = style_dim = 64)
+// Every AdaptiveInstance.fc / AdaptiveLayerNorm.fc (models/ada_norm.py:133,191) and every WN.cond_layer
+// (models/flow.py:38-40,67-68) of a stage is concatenated into one [J, 64] table: one launch per stage.
+// One wave per output row j; lanes = k.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) style_fc_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                        const float* __restrict__ s, float* __restrict__ out, int J, int K,
+                                                        int n_utt, int lds_s, int ld_out) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (j >= J) return;
+  float w0 = lane < K ? W[(long)j * K + lane] : 0.f;
+  float w1 = (lane + 64) < K ? W[(long)j * K + lane + 64] : 0.f;
+  const float bj = b[j];
+  for (int u = 0; u < n_utt; ++u) {
+    float v = lane < K ? w0 * s[(long)u * lds_s + lane] : 0.f;
+    if (lane + 64 < K) v += w1 * s[(long)u * lds_s + lane + 64];
+    v = wave_sum(v);
+    if (lane == 0) out[(long)u * ld_out + j] = v + bj;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm statistics folded with the AdaIN affine:  y = x*scale + shift with
+//   scale = rstd*(1+gamma), shift = beta - mean*scale      (models/ada_norm.py:135-139; eps 1e-5, biased var)
+// grid (ceil(C/32), n_utt); block 256 = 8 row lanes x 32 channels; two passes (mean, centred squares).
+// gb = style table row of this utterance: gamma at gcol0 + c, beta at gcol0 + C + c.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adain_stats_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
+                                                          const float* __restrict__ gb, int ld_gb, int gcol0, float eps,
+                                                          float* __restrict__ scale_shift, int ld_ss) {
+  __shared__ float red[8][33];
+  const int u = blockIdx.y;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const bool ok = c < C;
+  float acc = 0.f;
+  if (ok)
+    for (int r = lo + rl; r < hi; r += 8) acc += X[(long)r * ldx + c];
+  red[rl][threadIdx.x & 31] = acc;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mean += red[i][threadIdx.x & 31];
+  const float n = (float)(hi - lo);
+  mean /= n;
+  __syncthreads();
+  acc = 0.f;
+  if (ok)
+    for (int r = lo + rl; r < hi; r += 8) {
+      const float d = X[(long)r * ldx + c] - mean;
+      acc += d * d;
+    }
+  red[rl][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (rl == 0 && ok) {
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) var += red[i][threadIdx.x & 31];
+    var /= n;
+    const float rstd = rsqrtf(var + eps);
+    const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
+    const float sc = rstd * (1.0f + g);
+    scale_shift[(long)u * ld_ss + c] = sc;
+    scale_shift[(long)u * ld_ss + ld_ss / 2 + c] = be - mean * sc;
+  }
+}
+
+// y[row][c] = act(x*scale + shift) for c < C, 0 for C <= c < ldy.  grid (row chunks, n_utt).
+// snake: y = v + sin^2(alpha*v)/alpha (AdaptiveGeneratorBlock, models/ada_norm.py:114,117) when alpha != null.
+__global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int C,
+                                                          const int* __restrict__ seg_off, const float* __restrict__ scale_shift,
+                                                          int ld_ss, int act, const float* __restrict__ alpha) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int nv = ldy / 4;  // float4 per row
+  const long total = (long)(hi - lo) * nv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = lo + (int)(i / nv), c4 = (int)(i % nv) * 4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C) {
+      const float4 x = *reinterpret_cast<const float4*>(X + (long)r * ldx + c4);
+      const float* sc = scale_shift + (long)u * ld_ss + c4;
+      const float* sh = sc + ld_ss / 2;
+      float xv[4] = {x.x, x.y, x.z, x.w}, ov[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = 0.f;
+        if (c4 + k < C) {
+          v = xv[k] * sc[k] + sh[k];
+          if (alpha) {
+            const float al = alpha[c4 + k];
+            const float sn = sinf(al * v);
+            v = v + sn * sn / al;
+          } else {
+            v = act_apply(v, act);
+          }
+        }
+        ov[k] = v;
+      }
+      o = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    *reinterpret_cast<float4*>(Y + (long)r * ldy + c4) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row LayerNorm over channels (one wave per row), optionally style-adaptive, up to two outputs:
+//   yk = LN(x)*(g) + b ; adaptive: g = 1+gamma_u[c], b = beta_u[c]  (AdaptiveLayerNorm, ada_norm.py:193-201)
+//   static: g = gamma[c], b = beta[c]                               (text_encoder.LayerNorm :24-33, nn.LayerNorm)
+// Optional post ops: ReLU (prenet), row mask multiply.  C <= 2048, C % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+struct LnOut {
+  float* Y;
+  int ldy, ycol0;
+  const float* g;  // adaptive: style table (row u), gamma at gcol0 + c, beta at gcol0 + C + c ; static: gamma[c]
+  const float* b;  // static beta (ignored when adaptive)
+  int ld_g, gcol0;
+};
+__global__ void __launch_bounds__(256) row_layernorm_kernel(const float* __restrict__ X, int ldx, int C, int n_rows,
+                                                            const int* __restrict__ row_utt, float eps, int adaptive, int nout,
+                                                            LnOut o0, LnOut o1, int act) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* x = X + (long)row * ldx;
+  float4 v[8];
+  const int nv = C / 4;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = lane + i * 64;
+    v[i] = q < nv ? *reinterpret_cast<const float4*>(x + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = lane + i * 64;
+    if (q < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      ss += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  const int u = adaptive ? row_utt[row] : 0;
+  for (int k = 0; k < nout; ++k) {
+    const LnOut& o = k == 0 ? o0 : o1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = lane + i * 64;
+      if (q < nv) {
+        float4 g, b;
+        if (adaptive) {
+          const float* gp = o.g + (long)u * o.ld_g + o.gcol0 + q * 4;
+          g = *reinterpret_cast<const float4*>(gp);
+          b = *reinterpret_cast<const float4*>(gp + C);
+          g.x += 1.f; g.y += 1.f; g.z += 1.f; g.w += 1.f;
+        } else {
+          g = *reinterpret_cast<const float4*>(o.g + q * 4);
+          b = *reinterpret_cast<const float4*>(o.b + q * 4);
+        }
+        float4 y;
+        y.x = act_apply((v[i].x - mean) * rstd * g.x + b.x, act);
+        y.y = act_apply((v[i].y - mean) * rstd * g.y + b.y, act);
+        y.z = act_apply((v[i].z - mean) * rstd * g.z + b.z, act);
+        y.w = act_apply((v[i].w - mean) * rstd * g.w + b.w, act);
+        *reinterpret_cast<float4*>(o.Y + (long)row * o.ldy + o.ycol0 + q * 4) = y;
+      }
+    }
+  }
+}
+
+// row -> utterance id table (for kernels that walk rows flat)
+__global__ void row_utt_kernel(const int* __restrict__ seg_off, int n_utt, int* __restrict__ row_utt) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  for (int r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) row_utt[r] = u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise Conv1d along time (groups = C): y[r][c] = b[c] + sum_k w[c][k] x[r + k - pad][c], zero outside the
+// utterance (ConvNeXtBlock.dwconv, models/generator.py:449-455; conv_next.py:25-27; cross_post.0).
+// Block = 64 rows x 64 channels staged in LDS with halo; thread = (channel, 16-row strip).
+// Wt is tap-major [K][C] so a wave reads 64 consecutive channels.  Optional fused SiLU.
+// ---------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int C,
+                                                     const int* __restrict__ seg_off, const float* __restrict__ Wt,
+                                                     const float* __restrict__ bias, int K, int act) {
+  constexpr int RB = 64;
+  __shared__ float tile[(RB + KMAX - 1) * 64];
+  const int u = blockIdx.z;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int r0 = lo + blockIdx.y * RB;
+  if (r0 >= hi) return;
+  const int c0 = blockIdx.x * 64;
+  const int pad = (K - 1) / 2;
+  const int nrows = RB + K - 1;
+  for (int i = threadIdx.x; i < nrows * 16; i += 256) {
+    const int rr = i >> 4, c4 = (i & 15) * 4;
+    const int g = r0 - pad + rr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g >= lo && g < hi && c0 + c4 < C) v = *reinterpret_cast<const float4*>(X + (long)g * ldx + c0 + c4);
+    *reinterpret_cast<float4*>(&tile[rr * 64 + c4]) = v;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, strip = threadIdx.x >> 6;  // 4 strips of 16 rows
+  if (c0 + c >= C) return;
+  float acc[16];
+  const float bv = bias[c0 + c];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = bv;
+  for (int k = 0; k < K; ++k) {
+    const float w = Wt[(long)k * C + c0 + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += w * tile[(strip * 16 + i + k) * 64 + c];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + strip * 16 + i;
+    if (r < hi) Y[(long)r * ldy + c0 + c] = act_apply(acc[i], act);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRN (models/generator.py:496-499): Gx[u][c] = ||U[:, c]||_2 over the utterance's rows (from the per-tile
+// partial sums the pwconv1 GEMM epilogue wrote), Nx = Gx / (mean_c Gx + 1e-6).  GRN(U) = U*(gamma*Nx + 1) + beta
+// is folded into pwconv2:  W2_u[co][c] = W2[co][c] * (gamma[c]*Nx[u][c] + 1)   (beta goes into the bias at load).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) grn_scale_kernel(const float* __restrict__ part, int ld_ss, int ss_stride,
+                                                        const int* __restrict__ seg_off, const float* __restrict__ gamma, int C,
+                                                        float* __restrict__ scale, int ld_scale) {
+  __shared__ float red[4];
+  const int u = blockIdx.x;
+  const int nsub = (seg_off[u + 1] - seg_off[u] + 31) / 32;
+  float gsum = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int t = 0; t < nsub; ++t) s += part[((long)u * ss_stride + t) * ld_ss + c];
+    const float g = sqrtf(s);
+    scale[(long)u * ld_scale + c] = g;
+    gsum += g;
+  }
+  gsum = wave_sum(gsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsum;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+  const float inv = 1.0f / (mean + 1e-6f);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float g = scale[(long)u * ld_scale + c];
+    scale[(long)u * ld_scale + c] = gamma[c] * (g * inv) + 1.0f;
+  }
+}
+
+// Wu[u][row][k] = W[row][k] * scale[u][k]   (W packed [Npad][kc], one tap)
+__global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restrict__ W, const float* __restrict__ scale, int ld_scale,
+                                                           float* __restrict__ Wu, int npad, int kc) {
+  const int u = blockIdx.y;
+  const long total4 = (long)npad * kc / 4;
+  const int k4n = kc / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int k4 = (int)(i % k4n) * 4;
+    const float4 w = reinterpret_cast<const float4*>(W)[i];
+    const float4 s = *reinterpret_cast<const float4*>(scale + (long)u * ld_scale + k4);
+    reinterpret_cast<float4*>(Wu + (long)u * npad * kc)[i] = make_float4(w.x * s.x, w.y * s.y, w.z * s.z, w.w * s.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Length regulator part 2 + decoder front end (models/speech_predictor.py:88-97, models/decoder.py:48-51):
+//   frame t4 of utterance u takes token tok[t4>>2]           (alignment.repeat_interleave(4) then enc @ alignment)
+//   pitch/energy: nn.Upsample(scale 4, linear, align_corners=False) from the T-rate curves
+// Here: gather of the phoneme encoding into time-major rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ enc, int ld_enc, const int* __restrict__ src_row,
+                                                          float* __restrict__ Y, int ldy, int ycol0, int C, int n_rows) {
+  const int nv = C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)n_rows * nv; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / nv), c4 = (int)(i % nv) * 4;
+    *reinterpret_cast<float4*>(Y + (long)r * ldy + ycol0 + c4) = *reinterpret_cast<const float4*>(enc + (long)src_row[r] * ld_enc + c4);
+  }
+}
+
+// durations [sum P] (int) per utterance -> frame->token row map at rate `rep` (rep=1: T frames, rep=4: T4 frames).
+// One block per utterance: inclusive scan of durations in LDS (P <= 1024), then each frame binary-searches.
+// tok_off: token offsets [n_utt+1]; frm_off: frame offsets at this rate [n_utt+1] (= rep * sum of durations).
+__global__ void __launch_bounds__(256) frame_token_map_kernel(const int* __restrict__ dur, const int* __restrict__ tok_off,
+                                                              const int* __restrict__ frm_off, int rep, int* __restrict__ src_row) {
+  __shared__ int cum[1025];
+  const int u = blockIdx.x;
+  const int t0 = tok_off[u], P = tok_off[u + 1] - t0;
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int i = 0; i < P; ++i) {
+      a += dur[t0 + i];
+      cum[i] = a;
+    }
+  }
+  __syncthreads();
+  const int f0 = frm_off[u], nf = frm_off[u + 1] - f0;
+  for (int f = threadIdx.x; f < nf; f += 256) {
+    const int t = f / rep;  // frame at the duration rate
+    int lo = 0, hi = P - 1;
+    while (lo < hi) {  // first token with cum > t
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    src_row[f0 + f] = t0 + lo;
+  }
+}
+
+// Linear x4 upsample (align_corners=False) of a per-frame curve, per utterance.
+__global__ void __launch_bounds__(256) upsample4_kernel(const float* __restrict__ x, const int* __restrict__ off_T, const int* __restrict__ off_T4,
+                                                        float* __restrict__ y) {
+  const int u = blockIdx.y;
+  const int a0 = off_T[u], T = off_T[u + 1] - a0, b0 = off_T4[u];
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < 4 * T; o += gridDim.x * 256) {
+    float src = fmaxf(((float)o + 0.5f) * 0.25f - 0.5f, 0.0f);
+    const int i0 = (int)floorf(src);
+    const int i1 = min(i0 + 1, T - 1);
+    const float lam = src - (float)i0;
+    y[b0 + o] = (1.0f - lam) * x[a0 + i0] + lam * x[a0 + i1];
+  }
+}
+
+// Decoder front end: F0 = wn-conv1d(1->1,k3)(pitch), N likewise (decoder.py:48-49), written with the phoneme
+// encoding into the encode block's input [asr | F0 | N | 0..] and into the constant columns of both ping-pong
+// concat buffers [x(512) | asr_res(64) | F0 | N | 0..] (decoder.py:51,56).
+struct FrontArgs {
+  const float* asr; int ld_asr;      // [rows, 128]
+  const float* pitch; const float* energy;  // [rows]
+  float wf[3], bf, wn[3], bn;        // folded 3-tap filters
+  float* enc_in; int ld_enc;         // [rows, 160]
+  float* xa; float* xb; int ld_x;    // [rows, 608]
+  int c_asr, c_hidden, c_res;        // 128, 512, 64
+};
+__global__ void __launch_bounds__(256) decoder_front_kernel(FrontArgs a, const int* __restrict__ seg_off) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int nv = a.ld_enc / 4;
+  const long total = (long)(hi - lo) * nv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = lo + (int)(i / nv), c4 = (int)(i % nv) * 4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < a.c_asr) {
+      o = *reinterpret_cast<const float4*>(a.asr + (long)r * a.ld_asr + c4);
+    } else if (c4 == a.c_asr) {
+      const float pm = r > lo ? a.pitch[r - 1] : 0.f, pp = r + 1 < hi ? a.pitch[r + 1] : 0.f;
+      const float em = r > lo ? a.energy[r - 1] : 0.f, ep = r + 1 < hi ? a.energy[r + 1] : 0.f;
+      const float f0 = a.wf[0] * pm + a.wf[1] * a.pitch[r] + a.wf[2] * pp + a.bf;
+      const float nn = a.wn[0] * em + a.wn[1] * a.energy[r] + a.wn[2] * ep + a.bn;
+      o.x = f0;
+      o.y = nn;
+      const int cc = a.c_hidden + a.c_res;  // 576: F0, N columns of the concat buffers; zero the tail
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        float* p = (w == 0 ? a.xa : a.xb) + (long)r * a.ld_x + cc;
+        p[0] = f0;
+        p[1] = nn;
+        for (int k = 2; k < a.ld_x - cc; ++k) p[k] = 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(a.enc_in + (long)r * a.ld_enc + c4) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout transposes at the module boundary: reference [B, C, T] (channel-major, equal T) <-> time-major rows
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) to_time_major_kernel(const float* __restrict__ X, int B, int C, int T, float* __restrict__ Y, int ldy,
+                                                            int ycol0, int zero_to) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < T) ? X[((long)b * C + c) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < T && c < zero_to) Y[((long)b * T + t) * ldy + ycol0 + c] = tile[tx][i];
+  }
+}
+__global__ void __launch_bounds__(256) to_channel_major_kernel(const float* __restrict__ X, int ldx, int xcol0, int B, int C, int T,
+                                                               float* __restrict__ Y) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    tile[i][tx] = (c < C && t < T) ? X[((long)b * T + t) * ldx + xcol0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    if (c < C && t < T) Y[((long)b * C + c) * T + t] = tile[tx][i];
+  }
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace stts

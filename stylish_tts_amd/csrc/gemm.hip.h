@@ -1,0 +1,353 @@
+// conv_gemm_f32: the dense contraction of the hot path (Conv1d k=1..7 and Linear) on the gfx950
+// f32-input matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 accumulate chain).
+//
+// Replaces every F.conv1d / nn.Linear on the reference's frame-rate path
+// (models/ada_norm.py:158-163 conv1/conv2/conv1x1, models/flow.py:39-60,182-192 WN + projections,
+// models/generator.py:344-386 prior/projector/output convs, :462-467 ConvNeXt pwconv1/2).
+//
+// Data layout (HBM): activations are TIME-MAJOR packed rows  X[row = utterance offset + frame][channel],
+// leading dimension a multiple of 32 floats (128 B rows, zero padded).  Weights are packed
+// W[cout_padded][tap][cin_padded] so that the contraction index (tap, cin) is contiguous for both MFMA
+// operands.  A conv tap is a ROW shift of X, so every LDS/VGPR access stays 16-byte aligned; utterance
+// boundaries provide the conv zero padding (rows outside [seg_off[u], seg_off[u+1]) read as 0).
+//
+// Tiling: block = BN time rows x BM output channels, WARPS_N x WARPS_M waves of 64 lanes; each wave owns
+// (BN/WARPS_N) x (BM/WARPS_M) as 32x32 accumulator tiles (rows = time on the A operand, cols = cout on the
+// B operand, so a store instruction writes 32 consecutive output channels = 128 B).  K advances 32
+// channels per iteration per (segment, tap); tiles are staged global -> VGPR -> LDS (double buffered, one
+// barrier per iteration) with a 16-byte-slot XOR swizzle (slot ^= (row>>1)&7) that makes both the
+// ds_write_b128 and the ds_read_b128 fragment reads conflict-free (guide §LDS, 64-bank b128 groups).
+// Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
+// epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
+#pragma once
+#include "common.h"
+
+namespace stts {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;  // native vector: stays in VGPRs (HIP's float4 struct copies via memcpy)
+
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_LRELU = 4 };
+enum Epi {
+  EPI_STORE = 0,      // Y = (act(acc + bias) [+ R]) * alpha ; optional per-tile sum of squares
+  EPI_GATE = 1,       // paired: Y = tanh(a + g[utt][c]) * sigmoid(b + g[utt][C + c])      (flow.py:7-14)
+  EPI_SPLIT_ACC = 2,  // cols < nsplit: D0 (+)= v ; cols >= nsplit: D1 (+)= v                 (flow.py:80-87)
+  EPI_COUPLE = 3,     // paired: Z1 = (Z1 - a) * exp(-b)                                      (flow.py:209)
+  EPI_PRIOR = 4,      // paired: Z = a + noise * exp(b)                                       (flow.py:314)
+};
+
+struct GemmSeg {
+  const float* X;     // time-major activations
+  const float* W;     // packed [Npad][ntaps][kc]
+  long w_utt_stride;  // floats between per-utterance copies of W (0: shared)
+  int ldx, xcol0, kc, ntaps, dil, pad;
+};
+
+struct GemmArgs {
+  GemmSeg seg[3];
+  int nseg;
+  const int* seg_off;  // device [n_utt + 1], rows
+  int N;               // output channels actually stored (paired epilogues: channels of the result)
+  const float* bias;   // [Npad] in packed row order, may be null
+  // EPI_STORE
+  float* Y;
+  int ldy, ycol0;
+  const float* R;
+  int ldr, rcol0;
+  float alpha;
+  int act;
+  float* sumsq_part;  // optional: [utt * ss_stride + (32-row sub-tile index within the utterance)][ld_ss]
+  int ld_ss, ss_stride;
+  // EPI_GATE
+  const float* gate;  // [n_utt][ld_gate]; a-part at gcol0 + c, b-part at gcol0 + gC + c
+  int ld_gate, gcol0, gC;
+  // EPI_SPLIT_ACC
+  float* D0;
+  float* D1;
+  int ldd0, ldd1, nsplit, acc0, acc1;
+  // EPI_COUPLE / EPI_PRIOR
+  float* Z;
+  int ldz, zcol0;
+  const float* noise;
+  int ldnoise;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_SILU: return v / (1.0f + __expf(-v));
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_LRELU: return v >= 0.0f ? v : 0.2f * v;
+    default: return v;
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const GemmArgs a) {
+  constexpr int NT = WARPS_M * WARPS_N * 64;
+  constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
+  constexpr int TR = WR / 32, TC = WC / 32;
+  constexpr int XL = BN * 8 / NT, WL = BM * 8 / NT;
+  static_assert(WR % 32 == 0 && WC % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert((BN * 8) % NT == 0 && (BM * 8) % NT == 0, "tile loads must divide over the block");
+  static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
+  __shared__ f32x4 lds[2 * (BN + BM) * 8];
+
+  const int utt = blockIdx.z;
+  const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
+  const int row0 = lo + blockIdx.y * BN;
+  if (row0 >= hi) return;
+  const int m0 = blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid / WARPS_M, wm = wid % WARPS_M;
+
+  f32x16 acc[TR][TC];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 xr[XL], wr[WL];
+  // iteration cursor of the NEXT tile to load.  The current segment lives in scalar registers: indexing
+  // a.seg[] with a run-time value would make the compiler copy the kernarg struct to scratch / LDS.
+  int s = 0, tap = 0, chunk = 0;
+  GemmSeg g = a.seg[0];
+  auto next_seg = [&]() {
+    if (s == 1) g = a.seg[1];
+    else if (s == 2) g = a.seg[2];
+  };
+
+  auto gload = [&]() {
+    const int shift = (tap - g.pad) * g.dil;
+    const float* xb = g.X + g.xcol0 + chunk * 32;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx >> 3, sl = idx & 7;
+      const int grow = row0 + r + shift;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (grow >= lo && grow < hi) v = *reinterpret_cast<const f32x4*>(xb + (long)grow * g.ldx + sl * 4);
+      xr[i] = v;
+    }
+    const float* wb = g.W + (long)utt * g.w_utt_stride + ((long)m0 * g.ntaps + tap) * g.kc + chunk * 32;
+    const long wrow = (long)g.ntaps * g.kc;
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + i * NT;
+      const int n = idx >> 3, sl = idx & 7;
+      wr[i] = *reinterpret_cast<const f32x4*>(wb + n * wrow + sl * 4);
+    }
+    // advance cursor
+    if (++chunk * 32 >= g.kc) {
+      chunk = 0;
+      if (++tap >= g.ntaps) {
+        tap = 0;
+        ++s;
+        next_seg();
+      }
+    }
+  };
+  auto lstore = [&](int b) {
+    f32x4* Xs = lds + b * (BN + BM) * 8;
+    f32x4* Ws = Xs + BN * 8;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx >> 3, sl = idx & 7;
+      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + i * NT;
+      const int n = idx >> 3, sl = idx & 7;
+      Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = wr[i];
+    }
+  };
+
+  int total = a.seg[0].ntaps * (a.seg[0].kc / 32);
+  if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / 32);
+  if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / 32);
+
+  gload();
+  lstore(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int it = 0; it < total; ++it) {
+    const bool more = it + 1 < total;
+    if (more) gload();
+    const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
+    const f32x4* Ws = Xs + BN * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int slot = 2 * kk + lh;
+      f32x4 xa[TR], wb[TC];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int r = wn * WR + i * 32 + l31;
+        xa[i] = Xs[r * 8 + (slot ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        const int c = wm * WC + j * 32 + l31;
+        wb[j] = Ws[c * 8 + (slot ^ ((c >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].x, wb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].y, wb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, wb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) lstore((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // acc[i][j][r]: row = wn*WR + i*32 + (r&3) + 8*(r>>2) + 4*lh ; col = wm*WC + j*32 + l31
+  const int nvalid = hi - row0;  // rows of this tile inside the utterance
+  if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      const int n = m0 + wm * WC + j * 32 + l31;
+      const float bv = a.bias ? a.bias[n] : 0.0f;
+      const bool nok = n < a.N;
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = wn * WR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = act_apply(acc[i][j][r] + bv, a.act);
+          if (rl < nvalid && nok) {
+            const long grow = row0 + rl;
+            if (a.R) v += a.R[grow * a.ldr + a.rcol0 + n];
+            v *= a.alpha;
+            a.Y[grow * a.ldy + a.ycol0 + n] = v;
+            ss += v * v;
+          }
+        }
+        if (a.sumsq_part) {
+          ss += __shfl_xor(ss, 32, 64);
+          if (lh == 0 && nok) {
+            const long t = (long)utt * a.ss_stride + blockIdx.y * (BN / 32) + (wn * TR + i);
+            a.sumsq_part[t * a.ld_ss + n] = ss;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_SPLIT_ACC) {
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      const int n = m0 + wm * WC + j * 32 + l31;
+      const float bv = a.bias ? a.bias[n] : 0.0f;
+      if (n < a.N) {
+        float* D;
+        int ld, col, accum;
+        if (n < a.nsplit) {
+          D = a.D0; ld = a.ldd0; col = n; accum = a.acc0;
+        } else {
+          D = a.D1; ld = a.ldd1; col = n - a.nsplit; accum = a.acc1;
+        }
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wn * WR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (rl < nvalid) {
+              float* p = D + (long)(row0 + rl) * ld + col;
+              const float v = acc[i][j][r] + bv;
+              *p = accum ? *p + v : v;
+            }
+          }
+      }
+    }
+  } else {
+    // paired: within each 64-column group of the packed weight, tile 2p holds the 'a' rows and tile 2p+1
+    // the matching 'b' rows, so both halves of a gate sit in the same lane.
+#pragma unroll
+    for (int jp = 0; jp < TC / 2; ++jp) {
+      const int npk = m0 + wm * WC + jp * 64 + l31;         // packed index of the 'a' row
+      const int c = (npk >> 6) * 32 + (npk & 31);           // result channel
+      const float ba = a.bias ? a.bias[npk] : 0.0f;
+      const float bb = a.bias ? a.bias[npk + 32] : 0.0f;
+      if (c < a.N) {
+        float ga = 0.f, gb = 0.f;
+        if constexpr (EPI == EPI_GATE) {
+          ga = a.gate[(long)utt * a.ld_gate + a.gcol0 + c];
+          gb = a.gate[(long)utt * a.ld_gate + a.gcol0 + a.gC + c];
+        }
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wn * WR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (rl < nvalid) {
+              const long grow = row0 + rl;
+              const float va = acc[i][2 * jp][r] + ba, vb = acc[i][2 * jp + 1][r] + bb;
+              if constexpr (EPI == EPI_GATE) {
+                const float t = tanhf(va + ga);
+                const float sg = 1.0f / (1.0f + __expf(-(vb + gb)));
+                a.Y[grow * a.ldy + a.ycol0 + c] = t * sg;
+              } else if constexpr (EPI == EPI_COUPLE) {
+                float* p = a.Z + grow * a.ldz + a.zcol0 + c;
+                *p = (*p - va) * __expf(-vb);
+              } else {  // EPI_PRIOR
+                a.Z[grow * a.ldz + a.zcol0 + c] = va + a.noise[grow * a.ldnoise + c] * __expf(vb);
+              }
+            }
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------
+struct GemmTile {
+  int bm, bn;
+};
+
+template <int BM, int BN, int WM, int WN>
+inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows) {
+  dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt), block(WM * WN * 64);
+  switch (epi) {
+    case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE>), grid, block, 0, st, a); break;
+    case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC>), grid, block, 0, st, a); break;
+    default:
+      if constexpr (BM / WM >= 64) {
+        if (epi == EPI_GATE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE>), grid, block, 0, st, a);
+        else if (epi == EPI_COUPLE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR>), grid, block, 0, st, a);
+      }
+      break;
+  }
+}
+
+// npad: padded cout of the packed weight (multiple of 128).  max_rows: longest utterance (rows).
+// Tile choice: 128x128 when that already fills the chip, else smaller row tiles for more workgroups.
+inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, int force_tile = 0) {
+  STTS_CHECK(npad % 128 == 0, "conv_gemm: padded cout %d not a multiple of 128", npad);
+  for (int i = 0; i < a.nseg; ++i) {
+    STTS_CHECK(a.seg[i].kc % 32 == 0 && a.seg[i].ldx % 4 == 0 && a.seg[i].xcol0 % 4 == 0, "conv_gemm: segment %d misaligned (kc %d ldx %d xcol0 %d)", i,
+               a.seg[i].kc, a.seg[i].ldx, a.seg[i].xcol0);
+  }
+  const long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
+  int tile = force_tile;
+  if (tile == 0) tile = blocks128 >= 400 ? 1 : (blocks128 >= 100 ? 2 : 3);
+  switch (tile) {
+    case 1: launch_cfg<128, 128, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
+    case 2: launch_cfg<128, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
+    default: launch_cfg<128, 32, 2, 1>(st, a, epi, npad, n_utt, max_rows); break;
+  }
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace stts

@@ -1,0 +1,768 @@
+// Context, weight packing and stage orchestration (host side of the library).
+#pragma once
+#include <math.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/stylish_hip.h"
+#include "common.h"
+#include "elementwise.hip.h"
+#include "gemm.hip.h"
+#include "signal.hip.h"
+
+namespace stts {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t dim(int i) const { return shape[i]; }
+};
+
+struct PackedConv {
+  float* W = nullptr;
+  float* bias = nullptr;
+  int npad = 0, N = 0, kc = 0, ntaps = 1;
+};
+
+// one entry of a style-projection table
+struct StyleSlot {
+  int col0 = 0, C = 0;
+};
+
+struct StyleTable {
+  std::vector<float> hW, hb;  // host staging [J][K], [J]
+  float* W = nullptr;
+  float* b = nullptr;
+  int J = 0, K = 64;
+  int add(const HostTensor& w, const HostTensor& bias) {  // returns col0 (4-aligned)
+    while (J % 4) {
+      hW.insert(hW.end(), K, 0.f);
+      hb.push_back(0.f);
+      ++J;
+    }
+    const int c0 = J;
+    hW.insert(hW.end(), w.data.begin(), w.data.end());
+    hb.insert(hb.end(), bias.data.begin(), bias.data.end());
+    J += (int)bias.data.size();
+    return c0;
+  }
+  int ld() const { return round_up(J, 4); }
+};
+
+struct AdainBlockW {
+  int cin = 0, cout = 0, kcin = 0;  // kcin = cin padded to 32
+  PackedConv conv1, conv2, sc;      // sc.W == nullptr: identity shortcut
+  StyleSlot n1, n2;
+};
+
+struct FlowLayerW {
+  PackedConv pre, in[4], rs[4], proj;
+  int cond_col0 = 0;
+};
+
+struct ConvNextW {
+  float* dw_wt = nullptr;  // [K][C] tap-major
+  float* dw_b = nullptr;
+  int K = 0;
+  StyleSlot norm;
+  PackedConv pw1, pw2;  // pw2.bias already includes W2 @ grn.beta
+  float* grn_gamma = nullptr;
+};
+
+struct MrfW {
+  PackedConv c1[3], c2[3];
+  StyleSlot a1[3], a2[3];
+  float* alpha1[3];
+  float* alpha2[3];
+  int dil[3] = {1, 3, 5};
+  int channels = 0, kernel = 0;
+  StyleTable table;
+};
+
+}  // namespace stts
+
+struct stts_ctx {
+  stts_model_dims d;
+  int device = 0;
+  std::map<std::string, stts::HostTensor> host;
+  std::vector<void*> allocs;
+  int* d_err = nullptr;
+  bool frame_ready = false;
+  // shared tables
+  float* hann = nullptr;      // periodic Hann(win)
+  float2* twiddle = nullptr;  // exp(-2 pi i m / n_fft), m < n_fft/2
+  double2* twiddle64 = nullptr;
+  // decoder
+  float front_wf[3], front_bf, front_wn[3], front_bn;
+  stts::PackedConv asr_res;
+  stts::AdainBlockW dec[5];
+  stts::StyleTable dec_style;
+  // prior + flow
+  stts::PackedConv prior, post_flow;
+  stts::FlowLayerW flow[8];
+  stts::StyleTable flow_style;
+  // generator
+  stts::PackedConv amp_prior, phase_prior, proj_mel, proj_la, proj_ph, amp_out, phase_out;
+  stts::ConvNextW cnx[4];
+  stts::StyleSlot head_amp, head_phase;
+  stts::StyleTable gen_style;
+  // on-demand op caches (tests)
+  std::map<std::string, std::unique_ptr<stts::AdainBlockW>> op_blocks;
+  std::map<std::string, std::unique_ptr<stts::StyleTable>> op_tables;
+  std::map<std::string, std::unique_ptr<stts::MrfW>> op_mrf;
+};
+
+namespace stts {
+
+// ------------------------------------------------------------------------------------------------
+// small host utilities
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+inline int dev_upload(stts_ctx* c, const std::vector<T>& h, T** out) {
+  void* p = nullptr;
+  STTS_HIP(hipMalloc(&p, std::max<size_t>(h.size(), 1) * sizeof(T)));
+  c->allocs.push_back(p);
+  if (!h.empty()) STTS_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)p;
+  return 0;
+}
+
+inline const HostTensor* find(stts_ctx* c, const std::string& name) {
+  auto it = c->host.find(name);
+  return it == c->host.end() ? nullptr : &it->second;
+}
+#define STTS_GET(var, name)                                   \
+  const stts::HostTensor* var = stts::find(c, (name));        \
+  if (!var) return stts::fail("missing weight '%s'", std::string(name).c_str())
+
+// w = g * v / ||v||, norm over all dims but 0 (torch weight_norm dim=0; reference: models/decoder.py:35-45
+// parametrization keys original0/original1, models/flow.py:40,52,60 legacy keys weight_g/weight_v)
+inline HostTensor fold_weight_norm(const HostTensor& g, const HostTensor& v) {
+  HostTensor w;
+  w.shape = v.shape;
+  w.data.resize(v.data.size());
+  const int64_t rows = v.shape[0], per = (int64_t)v.data.size() / rows;
+  for (int64_t r = 0; r < rows; ++r) {
+    double s = 0;
+    for (int64_t i = 0; i < per; ++i) s += (double)v.data[r * per + i] * v.data[r * per + i];
+    const float scale = g.data[r] / (float)sqrt(s);
+    for (int64_t i = 0; i < per; ++i) w.data[r * per + i] = v.data[r * per + i] * scale;
+  }
+  return w;
+}
+
+// fetch a conv/linear weight by module path, folding whichever weight-norm flavour is present
+inline int get_weight(stts_ctx* c, const std::string& p, HostTensor* w) {
+  if (const HostTensor* g = find(c, p + ".parametrizations.weight.original0")) {
+    STTS_GET(v, p + ".parametrizations.weight.original1");
+    *w = fold_weight_norm(*g, *v);
+  } else if (const HostTensor* g2 = find(c, p + ".weight_g")) {
+    STTS_GET(v, p + ".weight_v");
+    *w = fold_weight_norm(*g2, *v);
+  } else {
+    STTS_GET(v, p + ".weight");
+    *w = *v;
+  }
+  if (w->shape.size() == 2) w->shape.push_back(1);  // Linear == conv k=1
+  return 0;
+}
+
+// Pack rows of a [cout][cin][k] weight: out[n'][tap][ci] for ci in [0,kc) taking input channel cin_lo+ci.
+// row_of[n'] = source row (or -1 for zero padding); bias follows the same row order.
+inline int pack_rows(stts_ctx* c, const HostTensor& w, const HostTensor* bias, const std::vector<int>& row_of, int cin_lo, int cin_n,
+                     int kc, int N, PackedConv* out, float scale = 1.0f) {
+  const int cin = (int)w.shape[1], k = (int)w.shape[2];
+  const int npad = (int)row_of.size();
+  std::vector<float> pw((size_t)npad * k * kc, 0.f), pb(npad, 0.f);
+  for (int n = 0; n < npad; ++n) {
+    const int r = row_of[n];
+    if (r < 0) continue;
+    for (int t = 0; t < k; ++t)
+      for (int ci = 0; ci < cin_n; ++ci) pw[((size_t)n * k + t) * kc + ci] = w.data[((size_t)r * cin + cin_lo + ci) * k + t] * scale;
+    if (bias) pb[n] = bias->data[r] * scale;
+  }
+  STTS_TRY(dev_upload(c, pw, &out->W));
+  STTS_TRY(dev_upload(c, pb, &out->bias));
+  out->npad = npad;
+  out->N = N;
+  out->kc = kc;
+  out->ntaps = k;
+  return 0;
+}
+
+inline std::vector<int> plain_rows(int cout) {
+  std::vector<int> r(round_up(cout, 128), -1);
+  for (int i = 0; i < cout; ++i) r[i] = i;
+  return r;
+}
+// paired packing: result channel ch has its 'a' row at a_lo+ch and its 'b' row at b_lo+ch; within every 64 packed rows
+// the first 32 are 'a' rows and the next 32 the matching 'b' rows (see EPI_GATE in gemm.hip.h).
+inline std::vector<int> paired_rows(int nres, int a_lo, int b_lo) {
+  std::vector<int> r(round_up(2 * nres, 128), -1);
+  for (int ch = 0; ch < nres; ++ch) {
+    const int g = ch / 32, q = ch % 32;
+    r[g * 64 + q] = a_lo + ch;
+    r[g * 64 + 32 + q] = b_lo + ch;
+  }
+  return r;
+}
+
+inline int pack_plain(stts_ctx* c, const std::string& p, bool has_bias, int cin_lo, int cin_n, PackedConv* out, float scale = 1.0f) {
+  HostTensor w;
+  STTS_TRY(get_weight(c, p, &w));
+  const HostTensor* b = has_bias ? find(c, p + ".bias") : nullptr;
+  if (has_bias && !b) return fail("missing weight '%s.bias'", p.c_str());
+  if (cin_n < 0) cin_n = (int)w.shape[1] - cin_lo;
+  return pack_rows(c, w, b, plain_rows((int)w.shape[0]), cin_lo, cin_n, round_up(cin_n, 32), (int)w.shape[0], out, scale);
+}
+
+inline int upload_table(stts_ctx* c, StyleTable* t) {
+  while (t->J % 4) {
+    t->hW.insert(t->hW.end(), t->K, 0.f);
+    t->hb.push_back(0.f);
+    ++t->J;
+  }
+  STTS_TRY(dev_upload(c, t->hW, &t->W));
+  STTS_TRY(dev_upload(c, t->hb, &t->b));
+  return 0;
+}
+
+inline int add_style(stts_ctx* c, StyleTable* t, const std::string& p, int C, StyleSlot* slot) {
+  STTS_GET(w, p + ".fc.weight");
+  STTS_GET(b, p + ".fc.bias");
+  STTS_CHECK((int)b->data.size() == 2 * C, "%s.fc has %zu outputs, expected %d", p.c_str(), b->data.size(), 2 * C);
+  slot->col0 = t->add(*w, *b);
+  slot->C = C;
+  return 0;
+}
+
+inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout, StyleTable* table, AdainBlockW* o) {
+  o->cin = cin;
+  o->cout = cout;
+  o->kcin = round_up(cin, 32);
+  STTS_TRY(pack_plain(c, p + ".conv1", true, 0, cin, &o->conv1));
+  STTS_TRY(pack_plain(c, p + ".conv2", true, 0, cout, &o->conv2));
+  if (find(c, p + ".conv1x1.parametrizations.weight.original0") || find(c, p + ".conv1x1.weight"))
+    STTS_TRY(pack_plain(c, p + ".conv1x1", false, 0, cin, &o->sc));
+  STTS_TRY(add_style(c, table, p + ".norm1", cin, &o->n1));
+  STTS_TRY(add_style(c, table, p + ".norm2", cout, &o->n2));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: frame-rate path
+// ------------------------------------------------------------------------------------------------
+inline int finalize_frame(stts_ctx* c) {
+  const stts_model_dims& d = c->d;
+  STTS_CHECK(d.n_fft == kNfft && d.win_length == kWin && d.hop_length / 4 == kHop && d.sample_rate == 24000,
+             "this build is specialised for n_fft 2048 / win 1200 / hop 300 / 24 kHz (model.yml defaults)");
+  STTS_CHECK(d.style_dim == 64 && d.inter_dim == 128 && d.dec_hidden == 512 && d.dec_residual == 64 && d.gen_hidden == 512 &&
+                 d.gen_input == 512 && d.gen_inter == 1536,
+             "this build is specialised for the default model.yml channel sizes");
+  const std::string sp = "speech_predictor.";
+  // tables
+  {
+    std::vector<float> h(kWin);
+    for (int i = 0; i < kWin; ++i) h[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / kWin));
+    STTS_TRY(dev_upload(c, h, &c->hann));
+    std::vector<float2> tw(kNfft / 2);
+    for (int i = 0; i < kNfft / 2; ++i) tw[i] = make_float2((float)cos(2.0 * M_PI * i / kNfft), (float)-sin(2.0 * M_PI * i / kNfft));
+    STTS_TRY(dev_upload(c, tw, &c->twiddle));
+    std::vector<double2> tw64(kNfft / 2);
+    for (int i = 0; i < kNfft / 2; ++i) tw64[i] = make_double2(cos(2.0 * M_PI * i / kNfft), -sin(2.0 * M_PI * i / kNfft));
+    STTS_TRY(dev_upload(c, tw64, &c->twiddle64));
+  }
+  // decoder (models/decoder.py:6-45)
+  {
+    HostTensor wf, wn;
+    STTS_TRY(get_weight(c, sp + "decoder.F0_conv", &wf));
+    STTS_TRY(get_weight(c, sp + "decoder.N_conv", &wn));
+    STTS_GET(bf, sp + "decoder.F0_conv.bias");
+    STTS_GET(bn, sp + "decoder.N_conv.bias");
+    for (int i = 0; i < 3; ++i) {
+      c->front_wf[i] = wf.data[i];
+      c->front_wn[i] = wn.data[i];
+    }
+    c->front_bf = bf->data[0];
+    c->front_bn = bn->data[0];
+    STTS_TRY(pack_plain(c, sp + "decoder.asr_res.0", true, 0, d.inter_dim, &c->asr_res));
+    STTS_TRY(pack_adain_block(c, sp + "decoder.encode", d.inter_dim + 2, d.dec_hidden, &c->dec_style, &c->dec[0]));
+    for (int i = 0; i < 4; ++i)
+      STTS_TRY(pack_adain_block(c, sp + "decoder.decode." + std::to_string(i), d.dec_hidden + 2 + d.dec_residual, d.dec_hidden,
+                                &c->dec_style, &c->dec[i + 1]));
+    STTS_TRY(upload_table(c, &c->dec_style));
+  }
+  // prior + flow + post_flow (models/flow.py, models/speech_predictor.py:36-62)
+  {
+    const int fh = d.dec_hidden / 4, half = fh / 2;
+    HostTensor wm, wl;
+    STTS_TRY(get_weight(c, sp + "prior_encoder.proj_mean", &wm));
+    STTS_TRY(get_weight(c, sp + "prior_encoder.proj_logstd", &wl));
+    STTS_GET(bm, sp + "prior_encoder.proj_mean.bias");
+    STTS_GET(bl, sp + "prior_encoder.proj_logstd.bias");
+    HostTensor wcat = wm, bcat = *bm;
+    wcat.data.insert(wcat.data.end(), wl.data.begin(), wl.data.end());
+    wcat.shape[0] = 2 * fh;
+    bcat.data.insert(bcat.data.end(), bl->data.begin(), bl->data.end());
+    STTS_TRY(pack_rows(c, wcat, &bcat, paired_rows(fh, 0, fh), 0, d.dec_hidden, d.dec_hidden, fh, &c->prior));
+    for (int f = 0; f < 8; ++f) {
+      const std::string q = sp + "flow.flows." + std::to_string(2 * f) + ".";
+      FlowLayerW& L = c->flow[f];
+      STTS_TRY(pack_plain(c, q + "pre", true, 0, half, &L.pre));
+      for (int i = 0; i < 4; ++i) {
+        HostTensor w;
+        STTS_TRY(get_weight(c, q + "enc.in_layers." + std::to_string(i), &w));
+        STTS_GET(b, q + "enc.in_layers." + std::to_string(i) + ".bias");
+        STTS_TRY(pack_rows(c, w, b, paired_rows(fh, 0, fh), 0, fh, fh, fh, &L.in[i]));
+        STTS_TRY(pack_plain(c, q + "enc.res_skip_layers." + std::to_string(i), true, 0, fh, &L.rs[i]));
+      }
+      HostTensor pm, pl;
+      STTS_TRY(get_weight(c, q + "proj_mean", &pm));
+      STTS_TRY(get_weight(c, q + "proj_logstd", &pl));
+      STTS_GET(pmb, q + "proj_mean.bias");
+      STTS_GET(plb, q + "proj_logstd.bias");
+      HostTensor pc = pm, pcb = *pmb;
+      pc.data.insert(pc.data.end(), pl.data.begin(), pl.data.end());
+      pc.shape[0] = 2 * half;
+      pcb.data.insert(pcb.data.end(), plb->data.begin(), plb->data.end());
+      STTS_TRY(pack_rows(c, pc, &pcb, paired_rows(half, 0, half), 0, fh, fh, half, &L.proj));
+      HostTensor cw;
+      STTS_TRY(get_weight(c, q + "enc.cond_layer", &cw));
+      STTS_GET(cb, q + "enc.cond_layer.bias");
+      L.cond_col0 = c->flow_style.add(cw, *cb);
+    }
+    STTS_TRY(upload_table(c, &c->flow_style));
+    STTS_TRY(pack_plain(c, sp + "post_flow", true, 0, fh, &c->post_flow));
+  }
+  // generator (models/generator.py:340-438)
+  {
+    const std::string g = sp + "generator.";
+    const int h = d.gen_hidden, hp = h / 2;
+    STTS_TRY(pack_plain(c, g + "amp_prior_conv", true, 0, kBins, &c->amp_prior));
+    STTS_TRY(pack_plain(c, g + "phase_prior_conv", true, 0, kBins, &c->phase_prior));
+    STTS_TRY(pack_plain(c, g + "projector", true, 0, d.gen_input, &c->proj_mel));
+    STTS_TRY(pack_plain(c, g + "projector", false, d.gen_input, hp, &c->proj_la));
+    STTS_TRY(pack_plain(c, g + "projector", false, d.gen_input + hp, hp, &c->proj_ph));
+    STTS_TRY(pack_plain(c, g + "amp_output_conv", true, 0, h + hp, &c->amp_out));
+    STTS_TRY(pack_plain(c, g + "phase_output_conv", true, 0, h + hp, &c->phase_out));
+    const int ks[4] = {31, 15, 7, 3};
+    for (int i = 0; i < 4; ++i) {
+      const std::string q = g + "convnext." + std::to_string(i) + ".";
+      ConvNextW& B = c->cnx[i];
+      STTS_GET(dw, q + "dwconv.weight");
+      STTS_GET(db, q + "dwconv.bias");
+      STTS_CHECK(dw->shape[2] == ks[i], "convnext.%d dwconv kernel %lld != %d", i, (long long)dw->shape[2], ks[i]);
+      B.K = ks[i];
+      std::vector<float> wt((size_t)B.K * h);
+      for (int ch = 0; ch < h; ++ch)
+        for (int k = 0; k < B.K; ++k) wt[(size_t)k * h + ch] = dw->data[(size_t)ch * B.K + k];
+      STTS_TRY(dev_upload(c, wt, &B.dw_wt));
+      STTS_TRY(dev_upload(c, db->data, &B.dw_b));
+      STTS_TRY(add_style(c, &c->gen_style, q + "norm", h, &B.norm));
+      STTS_TRY(pack_plain(c, q + "pwconv1", true, 0, h, &B.pw1));
+      // pwconv2 with GRN's beta folded into the bias: W2 (U*s + beta) + b2 = (W2*s) U + (W2 beta + b2)
+      HostTensor w2;
+      STTS_TRY(get_weight(c, q + "pwconv2", &w2));
+      STTS_GET(b2, q + "pwconv2.bias");
+      STTS_GET(gg, q + "grn.gamma");
+      STTS_GET(gb, q + "grn.beta");
+      HostTensor b2f = *b2;
+      const int ci = (int)w2.shape[1];
+      for (int r = 0; r < (int)w2.shape[0]; ++r) {
+        double s = 0;
+        for (int k = 0; k < ci; ++k) s += (double)w2.data[(size_t)r * ci + k] * gb->data[k];
+        b2f.data[r] = (float)((double)b2->data[r] + s);
+      }
+      STTS_TRY(pack_rows(c, w2, &b2f, plain_rows((int)w2.shape[0]), 0, ci, round_up(ci, 32), (int)w2.shape[0], &B.pw2));
+      STTS_TRY(dev_upload(c, gg->data, &B.grn_gamma));
+    }
+    STTS_TRY(add_style(c, &c->gen_style, g + "amp_final_layer_norm", h, &c->head_amp));
+    STTS_TRY(add_style(c, &c->gen_style, g + "phase_final_layer_norm", h, &c->head_phase));
+    STTS_TRY(upload_table(c, &c->gen_style));
+  }
+  c->frame_ready = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace bump allocator (caller-owned memory)
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+  char* base;
+  size_t cap, used = 0;
+  bool ok = true;
+  Arena(void* p, size_t n) : base((char*)p), cap(n) {}
+  template <typename T>
+  T* get(size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
+    if (used + bytes > cap) {
+      ok = false;
+      return nullptr;
+    }
+    T* p = (T*)(base + used);
+    used += bytes;
+    return p;
+  }
+};
+
+struct Seg {
+  int n_utt;
+  const int* host;
+  const int* dev;
+  int rows() const { return host[n_utt]; }
+  int max_len() const {
+    int m = 0;
+    for (int i = 0; i < n_utt; ++i) m = std::max(m, host[i + 1] - host[i]);
+    return m;
+  }
+};
+
+inline GemmArgs gemm_args(const Seg& s) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.seg_off = s.dev;
+  a.alpha = 1.0f;
+  return a;
+}
+inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, const PackedConv& w, int pad = -1, int dil = 1) {
+  GemmSeg& g = a.seg[i];
+  g.X = X;
+  g.W = w.W;
+  g.w_utt_stride = 0;
+  g.ldx = ldx;
+  g.xcol0 = xcol0;
+  g.kc = w.kc;
+  g.ntaps = w.ntaps;
+  g.dil = dil;
+  g.pad = pad >= 0 ? pad : (w.ntaps - 1) / 2;
+  if (a.nseg < i + 1) a.nseg = i + 1;
+}
+
+inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
+  hipLaunchKernelGGL(style_fc_kernel, dim3(ceil_div(t.J, 4)), dim3(256), 0, st, t.W, t.b, style, out, t.J, t.K, n_utt, t.K, t.ld());
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+inline dim3 rows_grid(const Seg& s, int per_row_work) {
+  const long total = (long)s.max_len() * per_row_work;
+  return dim3((unsigned)std::min<long>(std::max<long>(1, ceil_div((int)std::min<long>(total, 1 << 30), 256)), 512), s.n_utt);
+}
+
+// AdaptiveDecoderBlock (models/ada_norm.py:166-182).  x [rows, ldx] (cols >= cin may hold anything when
+// kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
+// scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [n_utt, 2*max(kcin,cout)]
+inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
+                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0) {
+  const int ldss = 2 * std::max(B.kcin, B.cout);
+  const int ml = s.max_len();
+  // norm1 -> LeakyReLU
+  hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(B.cin, 32), s.n_utt), dim3(256), 0, st, x, ldx, B.cin, s.dev, style_out, ld_style,
+                     B.n1.col0, 1e-5f, ss, ldss);
+  hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, B.kcin / 4), dim3(256), 0, st, x, ldx, act1, B.kcin, B.cin, s.dev, ss, ldss,
+                     (int)ACT_LRELU, (const float*)nullptr);
+  GemmArgs a = gemm_args(s);
+  set_seg(a, 0, act1, B.kcin, 0, B.conv1);
+  a.N = B.cout;
+  a.bias = B.conv1.bias;
+  a.Y = hbuf;
+  a.ldy = B.cout;
+  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
+  // norm2 -> LeakyReLU
+  hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(B.cout, 32), s.n_utt), dim3(256), 0, st, hbuf, B.cout, B.cout, s.dev, style_out,
+                     ld_style, B.n2.col0, 1e-5f, ss, ldss);
+  hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, B.cout / 4), dim3(256), 0, st, hbuf, B.cout, act2, B.cout, B.cout, s.dev, ss, ldss,
+                     (int)ACT_LRELU, (const float*)nullptr);
+  // conv2 (+ learned 1x1 shortcut as a second K segment | + identity residual), / sqrt(2)
+  GemmArgs b = gemm_args(s);
+  set_seg(b, 0, act2, B.cout, 0, B.conv2);
+  if (B.sc.W) {
+    set_seg(b, 1, x, ldx, 0, B.sc);
+  } else {
+    b.R = x;
+    b.ldr = ldx;
+  }
+  b.N = B.cout;
+  b.bias = B.conv2.bias;
+  b.Y = y;
+  b.ldy = ldy;
+  b.alpha = 0.70710678118654752440f;
+  STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: Decoder.forward (models/decoder.py:47-60)
+// ------------------------------------------------------------------------------------------------
+inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const float* asr, int ld_asr, const float* pitch, const float* energy,
+                           const float* style, float* x_out, int ld_x, Arena& ws) {
+  const stts_model_dims& d = c->d;
+  const long R = s.rows();
+  const int ccat = d.dec_hidden + d.dec_residual + 2, ldcat = round_up(ccat, 32);  // 578 -> 608
+  const int cenc = d.inter_dim + 2, ldenc = round_up(cenc, 32);                    // 130 -> 160
+  float* enc_in = ws.get<float>(R * ldenc);
+  float* xa = ws.get<float>(R * ldcat);
+  float* xb = ws.get<float>(R * ldcat);
+  float* act1 = ws.get<float>(R * ldcat);
+  float* hbuf = ws.get<float>(R * d.dec_hidden);
+  float* act2 = ws.get<float>(R * d.dec_hidden);
+  float* ss = ws.get<float>((size_t)s.n_utt * 2 * ldcat);
+  float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
+  STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
+  STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
+  FrontArgs fa;
+  fa.asr = asr; fa.ld_asr = ld_asr; fa.pitch = pitch; fa.energy = energy;
+  for (int i = 0; i < 3; ++i) { fa.wf[i] = c->front_wf[i]; fa.wn[i] = c->front_wn[i]; }
+  fa.bf = c->front_bf; fa.bn = c->front_bn;
+  fa.enc_in = enc_in; fa.ld_enc = ldenc; fa.xa = xa; fa.xb = xb; fa.ld_x = ldcat;
+  fa.c_asr = d.inter_dim; fa.c_hidden = d.dec_hidden; fa.c_res = d.dec_residual;
+  hipLaunchKernelGGL(decoder_front_kernel, rows_grid(s, ldenc / 4), dim3(256), 0, st, fa, s.dev);
+  // asr_res = wn-conv1x1(asr) into the residual columns of both concat buffers (decoder.py:54)
+  for (float* dst : {xa, xb}) {
+    GemmArgs a = gemm_args(s);
+    set_seg(a, 0, asr, ld_asr, 0, c->asr_res);
+    a.N = d.dec_residual; a.bias = c->asr_res.bias; a.Y = dst; a.ldy = ldcat; a.ycol0 = d.dec_hidden;
+    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->asr_res.npad, s.n_utt, s.max_len()));
+  }
+  const int lds = c->dec_style.ld();
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss));
+  float* cur = xa;
+  float* nxt = xb;
+  for (int i = 1; i <= 4; ++i) {
+    float* dst = i == 4 ? x_out : nxt;
+    const int ldd = i == 4 ? ld_x : ldcat;
+    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss));
+    std::swap(cur, nxt);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: PriorEncoder + reverse flow + post_flow (models/flow.py:311-315, :132-151, :196-218, :63-88)
+// ------------------------------------------------------------------------------------------------
+inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const float* x, int ld_x, const float* style, const float* noise,
+                              float* mel, int ld_mel, float* z_prior_out, float* z_flow_out, Arena& ws) {
+  const stts_model_dims& d = c->d;
+  const long R = s.rows();
+  const int fh = d.dec_hidden / 4, half = fh / 2, ml = s.max_len();
+  float* z = ws.get<float>(R * fh);
+  float* hf = ws.get<float>(R * fh);
+  float* outf = ws.get<float>(R * fh);
+  float* acts = ws.get<float>(R * fh);
+  float* cond = ws.get<float>((size_t)s.n_utt * c->flow_style.ld());
+  STTS_CHECK(ws.ok, "prior_flow_forward: workspace too small");
+  STTS_TRY(run_style(st, c->flow_style, style, s.n_utt, cond));
+  {
+    GemmArgs a = gemm_args(s);
+    set_seg(a, 0, x, ld_x, 0, c->prior);
+    a.N = fh; a.bias = c->prior.bias; a.Z = z; a.ldz = fh; a.noise = noise; a.ldnoise = fh;
+    STTS_TRY(launch_conv_gemm(st, a, EPI_PRIOR, c->prior.npad, s.n_utt, ml));
+  }
+  if (z_prior_out) STTS_HIP(hipMemcpyAsync(z_prior_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // reversed(flows) = Flip, layer 7, Flip, layer 6, ..., Flip, layer 0: after k flips the roles of the halves swap,
+  // so layer f reads half p = (f odd) and updates the other half in place; after layer 0 the order is natural.
+  for (int f = 7; f >= 0; --f) {
+    const FlowLayerW& L = c->flow[f];
+    const int p = f & 1;
+    {
+      GemmArgs a = gemm_args(s);
+      set_seg(a, 0, z, fh, p * half, L.pre);
+      a.N = fh; a.bias = L.pre.bias; a.Y = hf; a.ldy = fh;
+      STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, L.pre.npad, s.n_utt, ml));
+    }
+    for (int i = 0; i < 4; ++i) {
+      GemmArgs g = gemm_args(s);
+      set_seg(g, 0, hf, fh, 0, L.in[i]);
+      g.N = fh; g.bias = L.in[i].bias; g.Y = acts; g.ldy = fh;
+      g.gate = cond; g.ld_gate = c->flow_style.ld(); g.gcol0 = L.cond_col0 + i * 2 * fh; g.gC = fh;
+      STTS_TRY(launch_conv_gemm(st, g, EPI_GATE, L.in[i].npad, s.n_utt, ml));
+      GemmArgs r = gemm_args(s);
+      set_seg(r, 0, acts, fh, 0, L.rs[i]);
+      r.N = L.rs[i].N; r.bias = L.rs[i].bias; r.nsplit = fh;
+      if (i < 3) {
+        r.D0 = hf; r.ldd0 = fh; r.acc0 = 1;
+        r.D1 = outf; r.ldd1 = fh; r.acc1 = i > 0;
+      } else {
+        r.D0 = outf; r.ldd0 = fh; r.acc0 = 1;
+        r.D1 = outf; r.ldd1 = fh; r.acc1 = 1;
+      }
+      STTS_TRY(launch_conv_gemm(st, r, EPI_SPLIT_ACC, L.rs[i].npad, s.n_utt, ml));
+    }
+    GemmArgs q = gemm_args(s);
+    set_seg(q, 0, outf, fh, 0, L.proj);
+    q.N = half; q.bias = L.proj.bias; q.Z = z; q.ldz = fh; q.zcol0 = (1 - p) * half;
+    STTS_TRY(launch_conv_gemm(st, q, EPI_COUPLE, L.proj.npad, s.n_utt, ml));
+  }
+  if (z_flow_out) STTS_HIP(hipMemcpyAsync(z_flow_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
+  GemmArgs a = gemm_args(s);
+  set_seg(a, 0, z, fh, 0, c->post_flow);
+  a.N = d.dec_hidden; a.bias = c->post_flow.bias; a.Y = mel; a.ldy = ld_mel;
+  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->post_flow.npad, s.n_utt, ml));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: harmonic source + STFT (models/generator.py:247-315, :32-44, :406-410)
+// ------------------------------------------------------------------------------------------------
+inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float* pitch, const float* noise, const float* init_phase,
+                         int batch_scope, float* prior_out, float* har_spec, float* har_phase, int ld, Arena& ws) {
+  const long R = s.rows();
+  double* prefix = ws.get<double>(R);
+  float* stats = ws.get<float>(2 * s.n_utt);
+  float* sig = prior_out ? prior_out : ws.get<float>(R * kHop);
+  STTS_CHECK(ws.ok, "harmonic_stft: workspace too small");
+  for (int u = 0; u < s.n_utt; ++u)
+    STTS_CHECK((long)(s.host[u + 1] - s.host[u]) * kHop > kNfft / 2, "utterance %d too short for reflect padding (%d frames; need > %d samples)", u,
+               s.host[u + 1] - s.host[u], kNfft / 2);
+  hipLaunchKernelGGL(pcph_prep_kernel, dim3(s.n_utt), dim3(256), 0, st, pitch, s.dev, prefix, stats);
+  hipLaunchKernelGGL(pcph_kernel, dim3(std::min(1024, ceil_div(s.max_len() * kHop, 256)), s.n_utt), dim3(256), 0, st, pitch, s.dev, s.n_utt,
+                     prefix, stats, noise, init_phase, batch_scope, sig, c->d_err);
+  hipLaunchKernelGGL(stft_kernel, dim3(s.max_len(), s.n_utt), dim3(256), 0, st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld);
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: vocoder body + iSTFT (models/generator.py:412-433)
+// ------------------------------------------------------------------------------------------------
+inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows, const int* row_utt, float eps, int adaptive, int nout,
+                     const LnOut& o0, const LnOut& o1, int act) {
+  hipLaunchKernelGGL(row_layernorm_kernel, dim3((unsigned)ceil_div((int)n_rows, 4)), dim3(256), 0, st, X, ldx, C, (int)n_rows, row_utt, eps,
+                     adaptive, nout, o0, o1, act);
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const float* mel, int ld_mel, const float* style, const float* har_spec,
+                           const float* har_phase, int ld_har, float* audio, float* logamp_out, float* phase_out, int ld_lp, Arena& ws) {
+  const stts_model_dims& d = c->d;
+  const long R = s.rows();
+  const int h = d.gen_hidden, hp = h / 2, hc = h + hp, inter = d.gen_inter, ml = s.max_len();
+  const int ldlp = round_up(kBins, 32);
+  float* headA = ws.get<float>(R * hc);
+  float* headP = ws.get<float>(R * hc);
+  float* xa = ws.get<float>(R * h);
+  float* xb = ws.get<float>(R * h);
+  float* dw = ws.get<float>(R * h);
+  float* nrm = ws.get<float>(R * h);
+  float* U = ws.get<float>(R * inter);
+  const int ss_stride = ceil_div(ml, 128) * 4;
+  float* part = ws.get<float>((size_t)s.n_utt * ss_stride * inter);
+  float* gscale = ws.get<float>((size_t)s.n_utt * inter);
+  float* w2u = ws.get<float>((size_t)s.n_utt * c->cnx[0].pw2.npad * inter);
+  float* sty = ws.get<float>((size_t)s.n_utt * c->gen_style.ld());
+  int* row_utt = ws.get<int>(R);
+  float* la = logamp_out ? logamp_out : ws.get<float>(R * ldlp);
+  float* ph = phase_out ? phase_out : ws.get<float>(R * ldlp);
+  const int ldl = logamp_out ? ld_lp : ldlp;
+  float* yw = ws.get<float>((R + s.n_utt) * kWin);
+  STTS_CHECK(ws.ok, "vocoder_forward: workspace too small");
+  STTS_CHECK(!logamp_out == !phase_out, "logamp_out and phase_out must be given together");
+  const int lds = c->gen_style.ld();
+  STTS_TRY(run_style(st, c->gen_style, style, s.n_utt, sty));
+  hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(ml, 256), s.n_utt), dim3(256), 0, st, s.dev, s.n_utt, row_utt);
+  // prior convs (generator.py:412-413) write straight into the concat slots of the two head inputs
+  {
+    GemmArgs a = gemm_args(s);
+    set_seg(a, 0, har_spec, ld_har, 0, c->amp_prior);
+    a.N = hp; a.bias = c->amp_prior.bias; a.Y = headA; a.ldy = hc; a.ycol0 = h;
+    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->amp_prior.npad, s.n_utt, ml));
+    GemmArgs b = gemm_args(s);
+    set_seg(b, 0, har_phase, ld_har, 0, c->phase_prior);
+    b.N = hp; b.bias = c->phase_prior.bias; b.Y = headP; b.ldy = hc; b.ycol0 = h;
+    STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_prior.npad, s.n_utt, ml));
+  }
+  // projector over cat[mel, logamp_prior, phase_prior] as three K segments (generator.py:414)
+  {
+    GemmArgs a = gemm_args(s);
+    set_seg(a, 0, mel, ld_mel, 0, c->proj_mel);
+    set_seg(a, 1, headA, hc, h, c->proj_la);
+    set_seg(a, 2, headP, hc, h, c->proj_ph);
+    a.N = h; a.bias = c->proj_mel.bias; a.Y = xa; a.ldy = h;
+    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->proj_mel.npad, s.n_utt, ml));
+  }
+  float* cur = xa;
+  float* nxt = xb;
+  for (int i = 0; i < 4; ++i) {
+    const ConvNextW& B = c->cnx[i];
+    hipLaunchKernelGGL((dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), 0, st, cur, h, dw, h, h, s.dev, B.dw_wt,
+                       B.dw_b, B.K, (int)ACT_NONE);
+    LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0}, o1{};
+    STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE));
+    GemmArgs a = gemm_args(s);
+    set_seg(a, 0, nrm, h, 0, B.pw1);
+    a.N = inter; a.bias = B.pw1.bias; a.Y = U; a.ldy = inter; a.act = ACT_SILU;
+    a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
+    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
+    hipLaunchKernelGGL(grn_scale_kernel, dim3(s.n_utt), dim3(256), 0, st, part, inter, ss_stride, s.dev, B.grn_gamma, inter, gscale, inter);
+    hipLaunchKernelGGL(scale_weight_kernel, dim3(256, s.n_utt), dim3(256), 0, st, B.pw2.W, gscale, inter, w2u, B.pw2.npad, B.pw2.kc);
+    GemmArgs b = gemm_args(s);
+    set_seg(b, 0, U, inter, 0, B.pw2);
+    b.seg[0].W = w2u;
+    b.seg[0].w_utt_stride = (long)B.pw2.npad * B.pw2.kc;
+    b.N = h; b.bias = B.pw2.bias; b.Y = nxt; b.ldy = h; b.R = cur; b.ldr = h;
+    STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.pw2.npad, s.n_utt, ml));
+    std::swap(cur, nxt);
+  }
+  // two AdaLN heads (eps 1e-5) into columns [0,512) of the head inputs (generator.py:417-423)
+  {
+    LnOut o0{headA, hc, 0, sty, nullptr, lds, c->head_amp.col0}, o1{headP, hc, 0, sty, nullptr, lds, c->head_phase.col0};
+    STTS_TRY(ln_launch(st, cur, h, h, R, row_utt, 1e-5f, 1, 2, o0, o1, ACT_NONE));
+  }
+  {
+    GemmArgs a = gemm_args(s);
+    set_seg(a, 0, headA, hc, 0, c->amp_out);
+    a.N = kBins; a.bias = c->amp_out.bias; a.Y = la; a.ldy = ldl;
+    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->amp_out.npad, s.n_utt, ml));
+    GemmArgs b = gemm_args(s);
+    set_seg(b, 0, headP, hc, 0, c->phase_out);
+    b.N = kBins; b.bias = c->phase_out.bias; b.Y = ph; b.ldy = ldl;
+    STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
+  }
+  hipLaunchKernelGGL(istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), 0, st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), 0, st, yw, s.dev, c->hann, audio);
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int max_len) {
+  // closed form upper bound: the largest stage (vocoder) + the stage hand-off buffers + per-buffer alignment slack
+  const stts_model_dims& d = c->d;
+  const size_t f = sizeof(float);
+  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f;
+  const size_t flow = (size_t)R * 128 * 4 * f;
+  const size_t src = (size_t)R * (8 + kHop * f);
+  const size_t voc = (size_t)R * ((512 + 256) * 2 + 512 * 4 + d.gen_inter + 1056 * 2 + 1 + kWin) * f + (size_t)n_utt * kWin * f;
+  const size_t per_utt = (size_t)n_utt * ((size_t)(ceil_div(max_len, 128) * 4 + 1) * d.gen_inter + 512 * (size_t)d.gen_inter + 32768) * f;
+  const size_t handoff = (size_t)R * (512 + 512 + 1056 * 2) * f;
+  return std::max(std::max(dec, flow), std::max(src, voc)) + handoff + per_utt + (size_t)64 * 4096;
+}
+
+inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* asr, int ld_asr, const float* pitch, const float* energy,
+                      const float* style, const float* prior_noise, const float* src_noise, const float* init_phase, int batch_scope,
+                      float* audio, void* wsp, size_t ws_bytes) {
+  const long R = s.rows();
+  Arena top(wsp, ws_bytes);
+  const int ldh = round_up(kBins, 32);
+  float* x = top.get<float>(R * 512);
+  float* mel = top.get<float>(R * 512);
+  float* hs = top.get<float>(R * ldh);
+  float* hp = top.get<float>(R * ldh);
+  STTS_CHECK(top.ok, "frame_path: workspace too small");
+  const size_t mark = top.used;
+  auto stage = [&]() {
+    Arena a((char*)wsp + mark, ws_bytes - mark);
+    return a;
+  };
+  { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, 512, a)); }
+  { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, 512, style, prior_noise, mel, 512, nullptr, nullptr, a)); }
+  { Arena a = stage(); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a)); }
+  { Arena a = stage(); STTS_TRY(vocoder_forward(c, st, s, mel, 512, style, hs, hp, ldh, audio, nullptr, nullptr, 0, a)); }
+  return 0;
+}
+
+}  // namespace stts

@@ -1,0 +1,269 @@
+// Harmonic source, STFT and iSTFT of the vocoder.
+//   generate_pcph      models/generator.py:247-315   (fp64 phase accumulator, <=16 harmonics)
+//   TorchSTFT.transform models/generator.py:32-44    torch.stft(n_fft 2048, hop 75, periodic Hann 1200 centred, reflect pad)
+//   TorchSTFT.inverse   models/generator.py:46-56    torch.istft(...) : irfft, window, overlap-add, /sum(w^2), trim
+// One workgroup per STFT frame: the transform runs entirely in LDS (Stockham radix-2, twiddles from a table
+// computed in fp64 on the host); forward in fp64 (see stft_kernel), inverse in fp32.  These kernels are HBM/LDS-bound and small next to the
+// contractions; they are written for exactness first (fp64 phase, full-precision exp/sin/cos).
+#pragma once
+#include "common.h"
+
+namespace stts {
+
+constexpr int kNfft = 2048, kHop = 75, kWin = 1200, kBins = 1025, kWinLo = (kNfft - kWin) / 2;  // 424
+constexpr float kSampleRate = 24000.0f;
+
+// ---------------------------------------------------------------------------------------------
+// generate_pcph, step 1: per-utterance statistics + exclusive fp64 prefix of the per-frame phase increment
+//   radious = f0.double()/sr ; cumsum over samples (generator.py:304-308); f0 is constant within a frame, so
+//   cumsum at sample (j, i) = prefix[j] + (i+1) * f0[j]/sr  (+ the shared random initial phase).
+// stats[u] = { min f0 over frames with f0 > 20 (inf if none), any frame voiced (f0 > 10) }
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pcph_prep_kernel(const float* __restrict__ f0, const int* __restrict__ seg_off,
+                                                        double* __restrict__ prefix, float* __restrict__ stats) {
+  __shared__ double part[256];
+  __shared__ float mn[256];
+  __shared__ int anyv[256];
+  const int u = blockIdx.x;
+  const int lo = seg_off[u], n = seg_off[u + 1] - lo;
+  const int per = (n + 255) / 256;
+  const int a = threadIdx.x * per, b = min(n, a + per);
+  double s = 0.0;
+  float m = INFINITY;
+  int av = 0;
+  for (int j = a; j < b; ++j) {
+    const float f = f0[lo + j];
+    s += (double)kHop * ((double)f / (double)kSampleRate);
+    if (f > 20.0f) m = fminf(m, f);
+    if (f > 10.0f) av = 1;
+  }
+  part[threadIdx.x] = s;
+  mn[threadIdx.x] = m;
+  anyv[threadIdx.x] = av;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double run = 0.0;
+    float mm = INFINITY;
+    int aa = 0;
+    for (int i = 0; i < 256; ++i) {
+      const double t = part[i];
+      part[i] = run;
+      run += t;
+      mm = fminf(mm, mn[i]);
+      aa |= anyv[i];
+    }
+    stats[2 * u] = mm;
+    stats[2 * u + 1] = (float)aa;
+  }
+  __syncthreads();
+  double run = part[threadIdx.x];
+  for (int j = a; j < b; ++j) {
+    prefix[lo + j] = run;
+    run += (double)kHop * ((double)f0[lo + j] / (double)kSampleRate);
+  }
+}
+
+// step 2: one thread per output sample.
+//   batch_scope != 0: harmonic count K from the minimum over ALL utterances of the call (what the reference does
+//   for a batched call, generator.py:285-287); 0: per utterance (= the reference called with B=1 per utterance).
+//   err[0] is set when some frame is voiced but no f0 exceeds 20 Hz (the reference raises there, generator.py:285).
+__global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0, const int* __restrict__ seg_off, int n_utt,
+                                                   const double* __restrict__ prefix, const float* __restrict__ stats,
+                                                   const float* __restrict__ noise, const float* __restrict__ init_phase, int batch_scope,
+                                                   float* __restrict__ out, int* __restrict__ err) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
+  float mnf = stats[2 * u];
+  int anyv = stats[2 * u + 1] > 0.5f;
+  if (batch_scope) {
+    for (int v = 0; v < n_utt; ++v) {
+      mnf = fminf(mnf, stats[2 * v]);
+      anyv |= stats[2 * v + 1] > 0.5f;
+    }
+  }
+  int K = 0;
+  if (anyv) {
+    if (isinf(mnf)) {
+      if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(err, 1);
+      K = 16;
+    } else {
+      K = min(16, (int)(12000.0 / (double)mnf));
+    }
+  }
+  const double ph0 = (double)init_phase[0];
+  const long nsamp = (long)nfr * kHop, base = (long)lo * kHop;
+  for (long sidx = (long)blockIdx.x * 256 + threadIdx.x; sidx < nsamp; sidx += (long)gridDim.x * 256) {
+    const int j = (int)(sidx / kHop), i = (int)(sidx % kHop);
+    const float f = f0[lo + j];
+    float val = 0.01f * noise[base + sidx];
+    if (f > 10.0f && K > 0) {
+      const double rad = ph0 + prefix[lo + j] + (double)(i + 1) * ((double)f / (double)kSampleRate);
+      const float nh = (kSampleRate * 0.5f) / f;
+      const float amp = 0.1f * sqrtf(2.0f / nh);
+      float acc = 0.f;
+      for (int k = 1; k <= K; ++k) {
+        if (f * (float)k <= kSampleRate * 0.5f) {
+          double t = rad * (double)k;
+          t -= floor(t);  // sin(2*pi*t) is 1-periodic; reduce in fp64 before the evaluation
+          acc += (float)sin(6.283185307179586476925286766559 * t);
+        }
+      }
+      val += amp * acc;
+    }
+    out[base + sidx] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// N-point complex FFT in LDS (Stockham autosort, radix 2), 256 threads.  tw[m * tw_scale] = exp(-2*pi*i*m/N)
+// for m < N/2 (forward); the inverse conjugates on the fly.  Input in `a`; returns the buffer holding the result.
+// ---------------------------------------------------------------------------------------------
+template <typename T2, int N, bool INVERSE>
+__device__ __forceinline__ T2* fft_lds(T2* a, T2* b, const T2* tw, int tw_scale) {
+  const int tid = threadIdx.x;
+  T2* in = a;
+  T2* out = b;
+#pragma unroll 1
+  for (int Ns = 1; Ns < N; Ns <<= 1) {
+    const int tstride = (N / 2) / Ns * tw_scale;
+#pragma unroll
+    for (int q = 0; q < N / 512; ++q) {
+      const int j = tid + q * 256;  // 0 .. N/2-1
+      const int k = j & (Ns - 1);
+      T2 w = tw[k * tstride];
+      if (INVERSE) w.y = -w.y;
+      const T2 x0 = in[j], x1 = in[j + N / 2];
+      T2 t;
+      t.x = x1.x * w.x - x1.y * w.y;
+      t.y = x1.x * w.y + x1.y * w.x;
+      const int j0 = ((j - k) << 1) + k;
+      T2 o0, o1;
+      o0.x = x0.x + t.x; o0.y = x0.y + t.y;
+      o1.x = x0.x - t.x; o1.y = x0.y - t.y;
+      out[j0] = o0;
+      out[j0 + Ns] = o1;
+    }
+    __syncthreads();
+    T2* tmp = in;
+    in = out;
+    out = tmp;
+  }
+  return in;
+}
+
+// Forward STFT of the harmonic prior + magnitude / atan2 phase (generator.py:406-410).
+// grid (max frames per utterance, n_utt); frame f of utterance u covers samples [75f - 600, 75f + 600) of the
+// reflect-padded signal.  Outputs time-major [rows, ld] with bins 0..1024; pad columns are zeroed.
+//
+// The transform runs in FP64 (real 2048-point FFT as one 1024-point complex FFT + split): atan2 is discontinuous
+// at the +-pi cut and meaningless at ~0 magnitude, so the SIGN of a rounding-level real/imaginary part decides a
+// 2*pi jump that the next conv sees linearly.  FP64 makes those signs those of the exact transform of the fp32
+// windowed samples; the work is negligible next to the contractions.
+__global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ sig, const int* __restrict__ seg_off, const float* __restrict__ hann,
+                                                   const double2* __restrict__ twiddle, float* __restrict__ spec, float* __restrict__ phase, int ld) {
+  constexpr int H = kNfft / 2;  // 1024
+  __shared__ double2 A[H], Bf[H];
+  const int u = blockIdx.y, f = blockIdx.x;
+  const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
+  if (f >= nfr) return;
+  const long L = (long)nfr * kHop;
+  const float* x = sig + (long)lo * kHop;
+  for (int n = threadIdx.x; n < H; n += 256) {
+    double v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int p = 2 * n + e;
+      double val = 0.0;
+      if (p >= kWinLo && p < kWinLo + kWin) {
+        long m = (long)f * kHop - kNfft / 2 + p;
+        if (m < 0) m = -m;
+        if (m >= L) m = 2 * (L - 1) - m;
+        val = (double)(x[m] * hann[p - kWinLo]);  // the product is formed in fp32 like torch.stft's windowing
+      }
+      v[e] = val;
+    }
+    A[n] = make_double2(v[0], v[1]);
+  }
+  __syncthreads();
+  const double2* Z = fft_lds<double2, H, false>(A, Bf, twiddle, 2);
+  float* so = spec + (long)(lo + f) * ld;
+  float* po = phase + (long)(lo + f) * ld;
+  for (int k = threadIdx.x; k < ld; k += 256) {
+    float m = 0.f, p = 0.f;
+    if (k < kBins) {
+      double re, im;
+      if (k == 0 || k == H) {
+        re = k == 0 ? Z[0].x + Z[0].y : Z[0].x - Z[0].y;
+        im = 0.0;
+      } else {
+        const double2 a = Z[k], b = Z[H - k];
+        const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);  // even part  (Z[k] + conj(Z[H-k]))/2
+        const double orr = 0.5 * (a.y + b.y), oi = -0.5 * (a.x - b.x);  // odd part   (Z[k] - conj(Z[H-k]))/(2i)
+        const double2 w = twiddle[k];                                 // exp(-2 pi i k / 2048)
+        re = er + orr * w.x - oi * w.y;
+        im = ei + orr * w.y + oi * w.x;
+      }
+      const float fr = (float)re, fi = (float)im;
+      m = sqrtf(fr * fr + fi * fi);
+      const float d = m + 1e-9f;
+      p = atan2f(fi / d, fr / d);
+    }
+    so[k] = m;
+    po[k] = p;
+  }
+}
+
+// Inverse: frame f in [0, T4] of utterance u (T4+1 frames; the last repeats row T4-1: F.pad replicate,
+// generator.py:425-426).  X = exp(logamp) * (cos(phase) + i sin(phase)) (generator.py:428-430), Hermitian
+// extension (imag of DC / Nyquist ignored like a C2R transform), inverse FFT, 1/N, window.
+// yw rows: utterance u starts at seg_off[u] + u.
+__global__ void __launch_bounds__(256) istft_frames_kernel(const float* __restrict__ logamp, const float* __restrict__ phase, int ld,
+                                                           const int* __restrict__ seg_off, const float* __restrict__ hann,
+                                                           const float2* __restrict__ twiddle, float* __restrict__ yw) {
+  __shared__ float2 A[kNfft], Bf[kNfft], tw[kNfft / 2];
+  const int u = blockIdx.y, f = blockIdx.x;
+  const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
+  if (f > nfr) return;
+  const long row = lo + min(f, nfr - 1);
+  for (int i = threadIdx.x; i < kNfft / 2; i += 256) tw[i] = twiddle[i];
+  for (int k = threadIdx.x; k < kBins; k += 256) {
+    const float a = expf(logamp[row * ld + k]);
+    const float p = phase[row * ld + k];
+    float re = a * cosf(p), im = a * sinf(p);
+    if (k == 0 || k == kNfft / 2) im = 0.f;
+    A[k] = make_float2(re, im);
+    if (k > 0 && k < kNfft / 2) A[kNfft - k] = make_float2(re, -im);
+  }
+  __syncthreads();
+  const float2* y = fft_lds<float2, kNfft, true>(A, Bf, tw, 1);
+  float* o = yw + (long)(lo + u + f) * kWin;
+  for (int i = threadIdx.x; i < kWin; i += 256) o[i] = y[kWinLo + i].x * (1.0f / kNfft) * hann[i];
+}
+
+// Overlap-add + window-envelope normalisation + centre trim + tanh (generator.py:432-433; torch.istft).
+// out sample s of utterance u (0 <= s < 75*T4) sits at t = s + 1024 of the untrimmed signal; frame f contributes
+// yw[f][t - 75 f - 424] while that index is in [0, 1200).
+__global__ void __launch_bounds__(256) istft_ola_kernel(const float* __restrict__ yw, const int* __restrict__ seg_off, const float* __restrict__ hann,
+                                                        float* __restrict__ audio) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
+  const long nsamp = (long)nfr * kHop;
+  const float* y = yw + (long)(lo + u) * kWin;
+  for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < nsamp; s += (long)gridDim.x * 256) {
+    const int t = (int)s + kNfft / 2 - kWinLo;  // offset inside frame 0's window
+    int f_hi = t / kHop;
+    if (f_hi > nfr) f_hi = nfr;
+    int f_lo = (t - (kWin - 1) + kHop - 1) / kHop;
+    if (t - (kWin - 1) < 0) f_lo = 0;
+    float acc = 0.f, env = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) {
+      const int i = t - f * kHop;
+      const float w = hann[i];
+      acc += y[(long)f * kWin + i];
+      env += w * w;
+    }
+    audio[(long)lo * kHop + s] = tanhf(acc / env);
+  }
+}
+
+}  // namespace stts

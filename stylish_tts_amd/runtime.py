@@ -1,0 +1,187 @@
+"""Host-side handle on the HIP library: context, weights, and the stage calls on torch device tensors.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic runs in libstylish_hip.so.
+Tensors at this level are TIME-MAJOR packed rows (see include/stylish_hip.h); the nn.Module shims in
+``modules.py`` convert from/to the reference's ``[B, C, T]`` layout at the module boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import load_model_config
+
+N_BINS_LD = 1056  # 1025 bins padded to a multiple of 32 floats
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Segments:
+    """Utterance row offsets (host int32 array + device copy)."""
+
+    def __init__(self, lengths: Sequence[int], device):
+        lengths = [int(x) for x in lengths]
+        self.lengths = lengths
+        self.host = np.zeros(len(lengths) + 1, np.int32)
+        self.host[1:] = np.cumsum(lengths)
+        self.dev = torch.from_numpy(self.host).to(device)
+        self.n = len(lengths)
+        self.rows = int(self.host[-1])
+        self.max_len = max(lengths)
+
+    @property
+    def host_ptr(self):
+        return self.host.ctypes.data_as(C.c_void_p)
+
+    def scaled(self, k: int) -> "Segments":
+        return Segments([x * k for x in self.lengths], self.dev.device)
+
+
+class HipModel:
+    """Owns a stts_ctx.  weights: {module name: {state_dict key: array}} for the five inference modules."""
+
+    def __init__(self, cfg=None, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipModel needs a GPU (MI355X); there is no CPU fallback in the product path")
+        self.lib = _lib.load()
+        self.cfg = cfg if cfg is not None else load_model_config()
+        self.device = torch.device("cuda", device)
+        self._dims = _lib.dims_from_config(self.cfg)
+        h = C.c_void_p()
+        _lib.check(self.lib.stts_ctx_create(C.byref(self._dims), device, C.byref(h)))
+        self.ctx = h
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.stts_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, weights: Mapping[str, Mapping[str, "np.ndarray | torch.Tensor"]], which: int = 1):
+        for mod, sd in weights.items():
+            self.load_state_dict(mod, sd)
+        self.finalize(which)
+
+    def load_state_dict(self, module: str, sd: Mapping[str, "np.ndarray | torch.Tensor"], prefix: str = ""):
+        for k, v in sd.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+            name = (module + "." if module else "") + prefix + k
+            _lib.check(self.lib.stts_load_weight(self.ctx, name.encode(), a.ctypes.data_as(C.c_void_p), shape, max(a.ndim, 1)))
+
+    def finalize(self, which: int = 1):
+        _lib.check(self.lib.stts_finalize_weights(self.ctx, which))
+
+    def check_status(self):
+        _lib.check(self.lib.stts_check_status(self.ctx, _stream()))
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, seg: Segments) -> torch.Tensor:
+        need = int(self.lib.stts_frame_workspace_bytes(self.ctx, seg.rows, seg.n, seg.max_len))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _f32(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ stages (time-major tensors)
+    def decoder(self, seg: Segments, asr, pitch, energy, style):
+        x = self._f32(seg.rows, 512)
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_decoder_forward(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(asr), asr.shape[1], _ptr(pitch),
+                                                 _ptr(energy), _ptr(style), _ptr(x), 512, _ptr(ws), ws.numel()))
+        return x
+
+    def prior_flow(self, seg: Segments, x, style, prior_noise, return_z=False):
+        mel = self._f32(seg.rows, 512)
+        zp = self._f32(seg.rows, 128) if return_z else None
+        zf = self._f32(seg.rows, 128) if return_z else None
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_prior_flow_forward(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], _ptr(style),
+                                                    _ptr(prior_noise), _ptr(mel), 512, _ptr(zp), _ptr(zf), _ptr(ws), ws.numel()))
+        return (mel, zp, zf) if return_z else mel
+
+    def harmonic_stft(self, seg: Segments, pitch, src_noise, init_phase, batch_scope=True, return_signal=False):
+        spec = self._f32(seg.rows, N_BINS_LD)
+        phase = self._f32(seg.rows, N_BINS_LD)
+        sig = self._f32(seg.rows * 75) if return_signal else None
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_harmonic_stft(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(pitch), _ptr(src_noise),
+                                               _ptr(init_phase), int(batch_scope), _ptr(sig), _ptr(spec), _ptr(phase), N_BINS_LD, _ptr(ws),
+                                               ws.numel()))
+        return (spec, phase, sig) if return_signal else (spec, phase)
+
+    def vocoder(self, seg: Segments, mel, style, har_spec, har_phase, return_spec=False):
+        audio = self._f32(seg.rows * 75)
+        la = self._f32(seg.rows, N_BINS_LD) if return_spec else None
+        ph = self._f32(seg.rows, N_BINS_LD) if return_spec else None
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_vocoder_forward(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(mel), mel.shape[1], _ptr(style),
+                                                 _ptr(har_spec), _ptr(har_phase), har_spec.shape[1], _ptr(audio), _ptr(la), _ptr(ph), N_BINS_LD,
+                                                 _ptr(ws), ws.numel()))
+        return (audio, la, ph) if return_spec else audio
+
+    def frame_path(self, seg: Segments, asr, pitch, energy, style, prior_noise, src_noise, init_phase, batch_scope=True, out=None):
+        audio = out if out is not None else self._f32(seg.rows * 75)
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_frame_path(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(asr), asr.shape[1], _ptr(pitch),
+                                            _ptr(energy), _ptr(style), _ptr(prior_noise), _ptr(src_noise), _ptr(init_phase), int(batch_scope),
+                                            _ptr(audio), _ptr(ws), ws.numel()))
+        return audio
+
+    # ------------------------------------------------------------------ layout bridge + single ops
+    def to_time_major(self, x_bct: torch.Tensor, ld: Optional[int] = None) -> torch.Tensor:
+        B, Cc, T = x_bct.shape
+        ld = ld or ((Cc + 31) // 32 * 32)
+        y = self._f32(B * T, ld)
+        _lib.check(self.lib.stts_to_time_major(_stream(), _ptr(x_bct.contiguous()), B, Cc, T, _ptr(y), ld))
+        return y
+
+    def to_channel_major(self, x: torch.Tensor, B: int, Cc: int, T: int) -> torch.Tensor:
+        y = self._f32(B, Cc, T)
+        _lib.check(self.lib.stts_to_channel_major(_stream(), _ptr(x), x.shape[1], B, Cc, T, _ptr(y)))
+        return y
+
+    def op_conv1d(self, seg: Segments, x, cin, w: np.ndarray, bias: Optional[np.ndarray], dil=1, act=0, force_tile=0):
+        cout, _, k = w.shape
+        ldy = (cout + 31) // 32 * 32
+        y = torch.zeros(seg.rows, ldy, dtype=torch.float32, device=self.device)
+        w = np.ascontiguousarray(w, np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        _lib.check(self.lib.stts_op_conv1d(_stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], cin, w.ctypes.data_as(C.c_void_p),
+                                           None if b is None else b.ctypes.data_as(C.c_void_p), cout, k, dil, act, _ptr(y), ldy, force_tile))
+        return y
+
+    def op_adain_block(self, prefix: str, seg: Segments, x, cin, cout, style):
+        y = self._f32(seg.rows, cout)
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_op_adain_block(self.ctx, _stream(), prefix.encode(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], cin,
+                                                cout, _ptr(style), _ptr(y), cout, _ptr(ws), ws.numel()))
+        return y
+
+    def op_mrf_block(self, prefix: str, seg: Segments, x, channels, kernel, style):
+        y = self._f32(seg.rows, channels)
+        ws = self.workspace(seg)
+        _lib.check(self.lib.stts_op_mrf_block(self.ctx, _stream(), prefix.encode(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], channels,
+                                              kernel, _ptr(style), _ptr(y), channels, _ptr(ws), ws.numel()))
+        return y

@@ -101,27 +101,35 @@ class Replay:
 
 
 class CutTape:
-    """Record where the reference's har_phase (the torch.atan2 at generator.py:408) lies on the ±π branch
-    cut, and with which sign: flat indices into [B, bins, T4] (after the last frame is dropped) + signs."""
+    """Record the reference's har_phase where it is ill-conditioned, so that a run being compared can adopt the
+    reference's value there (oracle.align_branch):
+      (a) on the atan2 branch cut: |phase| > pi - 2e-3 (all of frame 0's negative-real bins: the reflect-padded
+          first frame is even-symmetric so its spectrum is real up to FFT rounding);
+      (b) bins of negligible magnitude (< 1e-4) whose phase is rounding noise.
+    Stored as flat indices into [B, bins, T4] (after the last frame is dropped) + the reference's phase values."""
+
+    stft = None  # set to the generator's TorchSTFT instance
 
     def __enter__(self):
-        self._orig = torch.atan2
-        self.out = None
+        self._orig = CutTape.stft.transform
+        self.mag = self.phase = None
 
-        def inner(y, x):
-            self.out = self._orig(y, x)
-            return self.out
+        def inner(x):
+            mag, cx, sy = self._orig(x)
+            self.mag, self.phase = mag, torch.atan2(sy, cx)
+            return mag, cx, sy
 
-        torch.atan2 = inner
+        CutTape.stft.transform = inner
         return self
 
     def __exit__(self, *exc):
-        torch.atan2 = self._orig
+        CutTape.stft.transform = self._orig
 
     def hints(self):
-        ph = self.out[:, :, :-1].contiguous().numpy().reshape(-1)
-        idx = np.nonzero(np.abs(ph) > np.pi - 2e-3)[0].astype(np.int32)
-        return dict(cut_idx=idx, cut_sign=np.sign(ph[idx]).astype(np.int8))
+        ph = self.phase[:, :, :-1].contiguous().numpy().reshape(-1)
+        mg = self.mag[:, :, :-1].contiguous().numpy().reshape(-1)
+        idx = np.nonzero((np.abs(ph) > np.pi - 2e-3) | (mg < 1e-4))[0].astype(np.int32)
+        return dict(cut_idx=idx, cut_phase=ph[idx].astype(np.float32))
 
 
 def load_synth(module, name, cfg):
@@ -187,6 +195,7 @@ def main():
         TextStyleEncoder(mc.pitch_energy_predictor.inter_dim, mc.style_dim, mc.style_encoder), "pe_text_style_encoder", cfg
     )
     durproc = DurationProcessor(mc.duration_predictor.duration_classes, mc.duration_predictor.max_duration)
+    CutTape.stft = sp.generator.stft
 
     # ---------------- frame-rate modules at a reduced shape (T4 = 64) ----------------
     B, T4 = 1, 64

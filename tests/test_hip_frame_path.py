@@ -1,0 +1,273 @@
+"""GPU parity tests of the frame-rate hot path (decoder → prior/flow → harmonic source/STFT → vocoder → iSTFT)
+through the C-ABI, against (a) golden vectors produced by the reference and (b) the numpy oracle on seeded inputs.
+
+Tolerances (fp32): intermediate tensors 2e-4 of their max-abs; waveform sample-wise max-abs < 1e-3.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def hip(cfg, weights):
+    from stylish_tts_amd.runtime import HipModel
+
+    m = HipModel(cfg, 0)
+    m.load_weights({"speech_predictor": weights["speech_predictor"]}, which=1)
+    yield m
+    m.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def tm(x_bct, ld=None):
+    """numpy [B,C,T] -> device time-major [B*T, ld] (zero padded)."""
+    B, C, T = x_bct.shape
+    ld = ld or (C + 31) // 32 * 32
+    y = np.zeros((B * T, ld), np.float32)
+    y[:, :C] = x_bct.transpose(0, 2, 1).reshape(B * T, C)
+    return dev(y)
+
+
+def cm(y, B, C, T):
+    """device time-major -> numpy [B,C,T]."""
+    return y.cpu().numpy()[:, :C].reshape(B, T, C).transpose(0, 2, 1)
+
+
+def close(a, b, rtol=2e-4, atol=None, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-6)
+    tol = atol if atol is not None else rtol * scale
+    err = np.abs(a - b).max()
+    assert np.isfinite(a).all(), f"{what}: non-finite output"
+    assert err <= tol, f"{what}: max-abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
+    return err
+
+
+def segs(lengths):
+    from stylish_tts_amd.runtime import Segments
+
+    return Segments(lengths, torch.device("cuda", 0))
+
+
+# ------------------------------------------------------------------------------------------------ conv GEMM
+@pytest.mark.parametrize(
+    "cin,cout,k,dil,lengths,tile",
+    [
+        (128, 64, 1, 1, [64], 0),
+        (130, 512, 3, 1, [64], 0),
+        (578, 512, 3, 1, [200, 37, 129], 1),
+        (578, 512, 3, 1, [200, 37, 129], 2),
+        (578, 512, 3, 1, [200, 37, 129], 3),
+        (128, 256, 5, 1, [96, 96], 0),
+        (96, 1025, 7, 1, [50], 0),
+        (64, 130, 7, 3, [77, 5], 0),
+        (32, 32, 11, 5, [1, 300], 0),
+    ],
+)
+def test_conv1d_matches_oracle(hip, cin, cout, k, dil, lengths, tile):
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+
+    s = segs(lengths)
+    ld = (cin + 31) // 32 * 32
+    w = synth.normal(f"t.w.{cin}.{cout}.{k}", (cout, cin, k)) / np.sqrt(cin * k)
+    b = synth.normal(f"t.b.{cout}", (cout,))
+    xs = [synth.normal(f"t.x.{i}.{L}", (1, cin, L)) for i, L in enumerate(lengths)]
+    x = np.zeros((s.rows, ld), np.float32)
+    for i, xi in enumerate(xs):
+        x[s.host[i] : s.host[i + 1], :cin] = xi[0].T
+    # put NaN-free garbage in the pad columns: the packed weight is zero there
+    y = hip.op_conv1d(s, dev(x), cin, w.astype(np.float32), b, dil=dil, force_tile=tile).cpu().numpy()
+    for i, xi in enumerate(xs):
+        ref = O.conv1d(xi, w.astype(np.float32), b, padding=(k - 1) // 2 * dil, dilation=dil)[0].T
+        close(y[s.host[i] : s.host[i + 1], :cout], ref, rtol=1e-5, what=f"conv utt {i}")
+
+
+def test_layout_bridge_roundtrip(hip):
+    from stylish_tts_amd import synth
+
+    x = synth.normal("t.bridge", (3, 130, 77))
+    y = hip.to_time_major(dev(x), 160)
+    assert np.array_equal(y.cpu().numpy()[:, :130].reshape(3, 77, 130), x.transpose(0, 2, 1))
+    assert np.all(y.cpu().numpy()[:, 130:] == 0)
+    back = hip.to_channel_major(y, 3, 130, 77).cpu().numpy()
+    assert np.array_equal(back, x)
+
+
+# ------------------------------------------------------------------------------------------------ AdaIN block / decoder
+def test_adain_block_golden(hip):
+    g = load_golden("decoder")
+    s = segs([64])
+    y = hip.op_adain_block("speech_predictor.decoder.encode", s, tm(g["enc_in"]), 130, 512, dev(g["style"]))
+    close(cm(y, 1, 512, 64), g["enc_out"], what="AdaptiveDecoderBlock")
+
+
+def test_decoder_golden(hip):
+    g = load_golden("decoder")
+    s = segs([64])
+    x = hip.decoder(s, tm(g["asr"]), dev(g["pitch"][0]), dev(g["energy"][0]), dev(g["style"]))
+    close(cm(x, 1, 512, 64), g["x"], what="Decoder")
+
+
+def test_prior_flow_golden(hip):
+    from stylish_tts_amd import synth
+
+    g = load_golden("flow")
+    nz = synth.path_noise("frame64", 1, 64)
+    s = segs([64])
+    mel, zp, zf = hip.prior_flow(s, tm(g["x"]), dev(g["style"]), tm(nz["prior_noise"]), return_z=True)
+    close(cm(zp, 1, 128, 64), g["z"], what="PriorEncoder z")
+    close(cm(zf, 1, 128, 64), g["z_out"], what="reverse flow")
+    close(cm(mel, 1, 512, 64), g["mel"], what="post_flow")
+
+
+# ------------------------------------------------------------------------------------------------ source / STFT / vocoder
+def circ(a, b):
+    return np.abs(np.angle(np.exp(1j * (np.asarray(a, np.float64) - np.asarray(b, np.float64)))))
+
+
+def test_harmonic_stft_golden(hip):
+    from stylish_tts_amd import synth
+
+    g = load_golden("generator")
+    nz = synth.path_noise("frame64", 1, 64)
+    s = segs([64])
+    spec, phase, sig = hip.harmonic_stft(s, dev(g["pitch"][0]), dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)), True, True)
+    close(sig.cpu().numpy()[None], g["prior_signal"], atol=2e-6, what="generate_pcph")
+    close(cm(spec, 1, 1025, 64), g["har_spec"], atol=3e-5, what="STFT magnitude")
+    d = circ(cm(phase, 1, 1025, 64), g["har_phase"])
+    strong = g["har_spec"] > 1e-3
+    assert d[strong].max() < 5e-3, d[strong].max()
+    assert np.all(spec.cpu().numpy()[:, 1025:] == 0) and np.all(phase.cpu().numpy()[:, 1025:] == 0)
+
+
+@pytest.mark.parametrize("case", ["unvoiced", "low", "high", "transition", "batch2"])
+def test_pcph_edge_cases_golden(hip, case):
+    from stylish_tts_amd import synth
+
+    g = load_golden("pcph_edges")
+    f0 = g[f"{case}_f0"]
+    B, T = f0.shape
+    nz = synth.path_noise("pcph." + case, B, T)
+    s = segs([T] * B)
+    _, _, sig = hip.harmonic_stft(s, dev(f0.reshape(-1)), dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)), True, True)
+    hip.check_status()
+    close(sig.cpu().numpy().reshape(B, 1, -1), g[f"{case}_out"], atol=2e-6, what=case)
+
+
+def test_pcph_error_flag_when_voiced_but_nothing_above_20hz(hip):
+    from stylish_tts_amd import synth
+
+    T = 24
+    nz = synth.path_noise("x", 1, T)
+    s = segs([T])
+    hip.harmonic_stft(s, dev(np.full(T, 15.0, np.float32)), dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)))
+    with pytest.raises(RuntimeError, match="20 Hz"):
+        hip.check_status()
+    hip.check_status()  # flag is cleared after being reported
+
+
+def test_vocoder_golden(hip):
+    """Body + iSTFT with the reference's own har_spec / har_phase as input: everything downstream of the atan2
+    branch cut must match everywhere."""
+    g = load_golden("generator")
+    s = segs([64])
+    audio, la, ph = hip.vocoder(s, tm(g["mel"]), dev(g["style"]), tm(g["har_spec"], 1056), tm(g["har_phase"], 1056), return_spec=True)
+    close(cm(la, 1, 1025, 64), g["logamp"][:, :, :64], atol=2e-3, what="logamp")
+    close(cm(ph, 1, 1025, 64), g["phase"][:, :, :64], atol=2e-3, what="phase")
+    close(audio.cpu().numpy()[None, None], g["audio"], atol=1e-3, what="audio")
+
+
+def apply_hint(phase_dev, spec_dev, g, B, T4):
+    """Adopt the reference's har_phase at the bins it recorded as ill-conditioned (oracle.align_branch); every
+    replaced value must be the same angle mod 2*pi or belong to a negligible bin."""
+    from oracle import stylish_oracle as O
+
+    ph, sp = cm(phase_dev, B, 1025, T4), cm(spec_dev, B, 1025, T4)
+    ph, bad = O.align_branch(ph, (g["cut_idx"].astype(np.int64), g["cut_phase"].astype(np.float32)), sp, return_bad=True)
+    assert bad == 0, f"{bad} hinted bins disagree with the reference by more than a branch choice"
+    return tm(ph, 1056)
+
+
+def test_frame_path_3s_golden(hip):
+    """3 s utterance (T4 = 960): decoder → flow → source → STFT → vocoder vs the reference's waveform, with the
+    atan2 branch ties resolved the reference's way between the STFT and the vocoder stage."""
+    from stylish_tts_amd import synth
+
+    g = load_golden("frame_path_3s")
+    T4 = 960
+    s = segs([T4])
+    asr = tm(synth.normal("g3.asr", (1, 128, T4)))
+    pitch = dev(synth.pitch_curve("g3.pitch", 1, T4)[0])
+    energy = dev((synth.uniform("g3.energy", (1, T4)) * 2.0 + 2.0).astype(np.float32)[0])
+    style = dev((synth.normal("g3.style", (1, 64)) * 0.7).astype(np.float32))
+    nz = synth.path_noise("frame960", 1, T4)
+    x = hip.decoder(s, asr, pitch, energy, style)
+    close(cm(x, 1, 512, T4)[:, ::64, ::16], g["x_probe"], what="decoder probe")
+    mel = hip.prior_flow(s, x, style, tm(nz["prior_noise"]))
+    close(cm(mel, 1, 512, T4)[:, ::64, ::16], g["mel_probe"], what="mel probe")
+    spec, phase = hip.harmonic_stft(s, pitch, dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)))
+    audio = hip.vocoder(s, mel, style, spec, apply_hint(phase, spec, g, 1, T4))
+    close(audio.cpu().numpy()[None, None], g["audio"], atol=1e-3, what="3 s waveform")
+    # the fused entry point computes the same thing; away from the branch-cut frames it must agree with the staged run
+    fused = hip.frame_path(s, asr, pitch, energy, style, tm(nz["prior_noise"]), dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)))
+    ref = hip.vocoder(s, mel, style, spec, phase)
+    assert torch.equal(fused, ref)
+
+
+def test_frame_path_vs_oracle_ragged_batch(hip, weights):
+    """Mixed lengths in one call == the oracle run per utterance (B=1 semantics, SURVEY.md §7 'hard parts')."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+
+    w = weights["speech_predictor"]
+    lens = [40, 131, 76]
+    s = segs(lens)
+    per = []
+    for i, L in enumerate(lens):
+        per.append(
+            dict(
+                asr=synth.normal(f"r.asr{i}", (1, 128, L)),
+                pitch=synth.pitch_curve(f"r.p{i}", 1, L),
+                energy=(synth.uniform(f"r.e{i}", (1, L)) * 2 + 2).astype(np.float32),
+                style=(synth.normal(f"r.s{i}", (1, 64)) * 0.7).astype(np.float32),
+                nz=synth.path_noise(f"r{i}", 1, L),
+            )
+        )
+    init_phase = per[0]["nz"]["init_phase"]
+    cat = lambda k: np.concatenate([p[k][0].T if p[k].ndim == 3 else p[k][0] for p in per])  # noqa: E731
+    asr = dev(cat("asr"))
+    pitch, energy = dev(cat("pitch")), dev(cat("energy"))
+    style = dev(np.concatenate([p["style"] for p in per]))
+    pn = dev(np.concatenate([p["nz"]["prior_noise"][0].T for p in per]))
+    sn = dev(np.concatenate([p["nz"]["src_noise"].reshape(-1) for p in per]))
+    x = hip.decoder(s, asr, pitch, energy, style)
+    mel = hip.prior_flow(s, x, style, pn)
+    spec, phase = hip.harmonic_stft(s, pitch, sn, dev(init_phase.reshape(-1)), batch_scope=False)
+    audio = hip.vocoder(s, mel, style, spec, phase).cpu().numpy()
+    ph_np = phase.cpu().numpy()
+    for i, (L, p) in enumerate(zip(lens, per)):
+        nz = dict(p["nz"], init_phase=init_phase)
+        hint = ph_np[s.host[i] : s.host[i + 1], :1025].T[None]
+        a, _, _ = O.frame_path(p["asr"], p["pitch"], p["energy"], p["style"], nz, w, branch_hint=hint)
+        close(audio[75 * s.host[i] : 75 * s.host[i + 1]], a[0, 0], atol=1e-3, what=f"utterance {i} (len {L})")
+
+
+def test_mrf_block_golden(hip):
+    from stylish_tts_amd import params
+
+    g = load_golden("mrf_block")
+    sd = params.synth_state_dict(params.adaptive_generator_block_spec("", 128, 7, 64), 0, prefix="mrf.")
+    hip.load_state_dict("mrf", sd)
+    s = segs([96])
+    y = hip.op_mrf_block("mrf.", s, tm(g["x"]), 128, 7, dev(g["style"]))
+    close(cm(y, 1, 128, 96), g["y"], what="AdaptiveGeneratorBlock")

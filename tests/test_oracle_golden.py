@@ -9,7 +9,7 @@ from stylish_tts_amd import params, synth
 
 
 def hint(g):
-    return (g["cut_idx"].astype(np.int64), g["cut_sign"].astype(np.float32))
+    return (g["cut_idx"].astype(np.int64), g["cut_phase"].astype(np.float32))
 
 
 def close(a, b, rtol=2e-4, atol=None, what=""):
