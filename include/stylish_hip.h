@@ -112,6 +112,12 @@ int stts_upsample4(stts_ctx* ctx, void* stream, int n_utt, const int32_t* off_T_
 int stts_to_time_major(void* stream, const float* x_bct, int B, int C, int T, float* y, int ldy);
 int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, int T, float* y_bct);
 
+/* Measurement hook (bench.py roofline leg): between begin and end every conv_gemm_f32 launch is bracketed by
+ * HIP events on its own stream.  end() synchronises and returns the launch count, the summed kernel time and
+ * the summed ALGORITHMIC flops (2 * rows * cout * cin * taps, un-padded sizes). */
+int stts_profile_begin(void);
+int stts_profile_end(void* stream, int* launches, double* total_ms, double* total_flops);
+
 /* Single operators, exposed for parity tests (same kernels the stages use). */
 /* F.conv1d(stride 1, zero pad (k-1)/2*dil) on time-major rows; w is the reference layout [cout, cin, k] on the HOST. */
 int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,

@@ -190,6 +190,31 @@ int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, i
   API_END
 }
 
+// ------------------------------------------------------------------------------------------------ profiling
+int stts_profile_begin(void) {
+  gemm_profiler().begin();
+  return 0;
+}
+
+int stts_profile_end(void* stream, int* launches, double* total_ms, double* total_flops) {
+  API_BEGIN
+  GemmProfiler& p = gemm_profiler();
+  p.on = false;
+  STTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  double ms = 0, fl = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    float t = 0;
+    STTS_HIP(hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]));
+    ms += t;
+  }
+  for (double f : p.flops) fl += f;
+  if (launches) *launches = (int)(p.used / 2);
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  return 0;
+  API_END
+}
+
 // ------------------------------------------------------------------------------------------------ test operators
 int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,
                    const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile) {
@@ -319,3 +344,52 @@ int stts_op_mrf_block(stts_ctx* c, void* stream, const char* prefix, int n_utt, 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ kernel microbench
+// Times `iters` back-to-back launches of conv_gemm_f32 on synthetic data (tuning aid for tools/gemm_bench.py).
+extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int cin, int cout, int k, int tile, int iters, double* avg_ms) {
+  API_BEGIN
+  hipStream_t st = (hipStream_t)stream;
+  const long R = (long)n_utt * rows_per_utt;
+  const int kc = round_up(cin, 32), npad = round_up(cout, 128), ldy = round_up(cout, 32);
+  float *X, *W, *Y, *B;
+  int* so;
+  STTS_HIP(hipMalloc(&X, R * kc * sizeof(float)));
+  STTS_HIP(hipMalloc(&W, (size_t)npad * k * kc * sizeof(float)));
+  STTS_HIP(hipMalloc(&Y, R * ldy * sizeof(float)));
+  STTS_HIP(hipMalloc(&B, npad * sizeof(float)));
+  STTS_HIP(hipMalloc(&so, (n_utt + 1) * sizeof(int)));
+  std::vector<int> h(n_utt + 1);
+  for (int i = 0; i <= n_utt; ++i) h[i] = i * rows_per_utt;
+  STTS_HIP(hipMemcpy(so, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  // pseudo-random fill (zeros would flatter the clock: guide §5.4 rule 25)
+  {
+    std::vector<float> t((size_t)std::max<long>(R * kc, (long)npad * k * kc));
+    uint32_t s = 12345;
+    for (auto& v : t) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    STTS_HIP(hipMemcpy(X, t.data(), R * kc * sizeof(float), hipMemcpyHostToDevice));
+    STTS_HIP(hipMemcpy(W, t.data(), (size_t)npad * k * kc * sizeof(float), hipMemcpyHostToDevice));
+    STTS_HIP(hipMemset(B, 0, npad * sizeof(float)));
+  }
+  PackedConv pc;
+  pc.W = W; pc.bias = B; pc.npad = npad; pc.N = cout; pc.kc = kc; pc.ntaps = k; pc.cin_real = cin; pc.rows_real = cout;
+  Seg s{n_utt, h.data(), so};
+  GemmArgs a = gemm_args(s);
+  set_seg(a, 0, X, kc, 0, pc);
+  a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy;
+  hipEvent_t e0, e1;
+  STTS_HIP(hipEventCreate(&e0));
+  STTS_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, npad, n_utt, rows_per_utt, tile));
+  STTS_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, npad, n_utt, rows_per_utt, tile));
+  STTS_HIP(hipEventRecord(e1, st));
+  STTS_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  STTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = ms / iters;
+  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(B); (void)hipFree(so);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+  API_END
+}

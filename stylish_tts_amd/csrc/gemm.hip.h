@@ -20,6 +20,8 @@
 // Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
 // epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace stts {
@@ -41,12 +43,14 @@ struct GemmSeg {
   const float* W;     // packed [Npad][ntaps][kc]
   long w_utt_stride;  // floats between per-utterance copies of W (0: shared)
   int ldx, xcol0, kc, ntaps, dil, pad;
+  int kreal;  // un-padded input channels (host side: algorithmic FLOP accounting only)
 };
 
 struct GemmArgs {
   GemmSeg seg[3];
   int nseg;
   const int* seg_off;  // device [n_utt + 1], rows
+  int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int N;               // output channels actually stored (paired epilogues: channels of the result)
   const float* bias;   // [Npad] in packed row order, may be null
   // EPI_STORE
@@ -310,9 +314,36 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
-struct GemmTile {
-  int bm, bn;
+// Optional per-launch timing of the contraction kernel with HIP events on the launch stream (bench.py's
+// roofline leg).  Off by default: when off the launcher records nothing.
+struct GemmProfiler {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<double> flops;
+  size_t used = 0;
+  void begin() {
+    on = true;
+    used = 0;
+    flops.clear();
+  }
+  hipEvent_t next() {
+    if (used == ev.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      ev.push_back(e);
+    }
+    return ev[used++];
+  }
 };
+inline GemmProfiler& gemm_profiler() {
+  static GemmProfiler p;
+  return p;
+}
+inline double gemm_algorithmic_flops(const GemmArgs& a) {
+  double k = 0;
+  for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].kreal * a.seg[i].ntaps;
+  return 2.0 * (double)a.rows_total * (double)a.wrows * k;
+}
 
 template <int BM, int BN, int WM, int WN>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows) {
@@ -341,10 +372,16 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   const long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
   int tile = force_tile;
   if (tile == 0) tile = blocks128 >= 400 ? 1 : (blocks128 >= 100 ? 2 : 3);
+  GemmProfiler& prof = gemm_profiler();
+  if (prof.on) (void)hipEventRecord(prof.next(), st);
   switch (tile) {
     case 1: launch_cfg<128, 128, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
     case 2: launch_cfg<128, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
     default: launch_cfg<128, 32, 2, 1>(st, a, epi, npad, n_utt, max_rows); break;
+  }
+  if (prof.on) {
+    (void)hipEventRecord(prof.next(), st);
+    prof.flops.push_back(gemm_algorithmic_flops(a));
   }
   STTS_HIP(hipGetLastError());
   return 0;

@@ -25,6 +25,7 @@ struct PackedConv {
   float* W = nullptr;
   float* bias = nullptr;
   int npad = 0, N = 0, kc = 0, ntaps = 1;
+  int cin_real = 0, rows_real = 0;  // un-padded sizes (FLOP accounting)
 };
 
 // one entry of a style-projection table
@@ -190,6 +191,9 @@ inline int pack_rows(stts_ctx* c, const HostTensor& w, const HostTensor* bias, c
   out->N = N;
   out->kc = kc;
   out->ntaps = k;
+  out->cin_real = cin_n;
+  out->rows_real = 0;
+  for (int r : row_of) out->rows_real += r >= 0;
   return 0;
 }
 
@@ -424,6 +428,7 @@ inline GemmArgs gemm_args(const Seg& s) {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.seg_off = s.dev;
+  a.rows_total = s.rows();
   a.alpha = 1.0f;
   return a;
 }
@@ -438,6 +443,8 @@ inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, cons
   g.ntaps = w.ntaps;
   g.dil = dil;
   g.pad = pad >= 0 ? pad : (w.ntaps - 1) / 2;
+  g.kreal = w.cin_real;
+  if (i == 0) a.wrows = w.rows_real;
   if (a.nseg < i + 1) a.nseg = i + 1;
 }
 

@@ -1,0 +1,26 @@
+"""Tuning aid: TF/s of conv_gemm_f32 per layer shape and tile (runs on the GPU box)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stylish_tts_amd import _lib
+lib = C.CDLL(_lib.LIB_PATH)
+lib.stts_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+torch.zeros(1).cuda()
+shapes = [  # name, cin, cout, k
+    ("out_conv 768->1025 k7", 768, 1025, 7), ("out_conv 768->1024 k7", 768, 1024, 7),
+    ("pwconv1 512->1536", 512, 1536, 1), ("pwconv2 1536->512", 1536, 512, 1),
+    ("dec conv1 578->512 k3", 578, 512, 3), ("dec conv2 512->512 k3", 512, 512, 3),
+    ("prior 1025->256 k7", 1025, 256, 7), ("flow in 128->256 k5", 128, 256, 5), ("flow rs 128->256", 128, 256, 1),
+    ("square 4096 (1 utt)", 4096, 4096, 1),
+]
+B, T4 = int(os.environ.get("B", 8)), 960
+for name, cin, cout, k in shapes:
+    line = f"{name:26s}"
+    for tile in (1, 2, 3):
+        ms = C.c_double()
+        nu, rows = (1, 4096) if name.startswith("square") else (B, T4)
+        rc = lib.stts_bench_gemm(None, nu, rows, cin, cout, k, tile, 10, C.byref(ms))
+        assert rc == 0
+        fl = 2.0 * nu * rows * cout * cin * k
+        line += f"  tile{tile}: {ms.value*1e3:8.1f} us {fl/ms.value/1e9:6.1f} TF"
+    print(line, flush=True)
