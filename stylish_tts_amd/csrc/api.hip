@@ -242,11 +242,13 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   API_END
 }
 
-static int op_scratch(Arena& a, long R, int kc, int cout, int n_utt, float** act1, float** h, float** act2, float** ss, float** sty, int ld_sty) {
+static int op_scratch(Arena& a, const Seg& s, int kc, int cout, float** act1, float** h, float** act2, float** ss, float** sty, int ld_sty) {
+  const long R = s.rows();
+  const int n_utt = s.n_utt;
   *act1 = a.get<float>(R * kc);
   *h = a.get<float>(R * cout);
   *act2 = a.get<float>(R * cout);
-  *ss = a.get<float>((size_t)n_utt * 2 * std::max(kc, cout));
+  *ss = a.get<float>(adain_part_floats(s, std::max(kc, cout)));
   *sty = a.get<float>((size_t)n_utt * ld_sty);
   STTS_CHECK(a.ok, "op: workspace too small");
   return 0;
@@ -272,7 +274,7 @@ int stts_op_adain_block(stts_ctx* c, void* stream, const char* prefix, int n_utt
   Seg s{n_utt, seg_off_host, seg_off_dev};
   Arena a(ws, ws_bytes);
   float *act1, *h, *act2, *ss, *sty;
-  STTS_TRY(op_scratch(a, s.rows(), B.kcin, B.cout, n_utt, &act1, &h, &act2, &ss, &sty, T.ld()));
+  STTS_TRY(op_scratch(a, s, B.kcin, B.cout, &act1, &h, &act2, &ss, &sty, T.ld()));
   STTS_TRY(run_style(st, T, style, n_utt, sty));
   return run_adain_block(st, s, B, sty, T.ld(), x, ldx, y, ldy, act1, h, act2, ss);
   API_END
@@ -310,7 +312,7 @@ int stts_op_mrf_block(stts_ctx* c, void* stream, const char* prefix, int n_utt, 
   float* cur = a.get<float>(R * channels);
   float* t1 = a.get<float>(R * channels);
   float* t2 = a.get<float>(R * channels);
-  float* ss = a.get<float>((size_t)n_utt * 2 * channels);
+  float* ss = a.get<float>(adain_part_floats(s, channels));
   float* sty = a.get<float>((size_t)n_utt * M.table.ld());
   STTS_CHECK(a.ok, "op_mrf_block: workspace too small");
   STTS_TRY(run_style(st, M.table, style, n_utt, sty));
@@ -318,18 +320,12 @@ int stts_op_mrf_block(stts_ctx* c, void* stream, const char* prefix, int n_utt, 
   const int ml = s.max_len(), lds = M.table.ld();
   // 3 x { AdaIN -> Snake -> dilated conv -> AdaIN -> Snake -> conv -> + x }  (models/ada_norm.py:109-120)
   for (int i = 0; i < 3; ++i) {
-    hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(channels, 32), n_utt), dim3(256), 0, st, cur, channels, channels, s.dev, sty, lds,
-                       M.a1[i].col0, 1e-5f, ss, 2 * channels);
-    hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, channels / 4), dim3(256), 0, st, cur, channels, t1, channels, channels, s.dev, ss,
-                       2 * channels, (int)ACT_NONE, (const float*)M.alpha1[i]);
+    STTS_TRY(run_adain(st, s, cur, channels, channels, t1, channels, sty, lds, M.a1[i].col0, ACT_NONE, M.alpha1[i], ss));
     GemmArgs g1 = gemm_args(s);
     set_seg(g1, 0, t1, channels, 0, M.c1[i], (kernel - 1) / 2, M.dil[i]);
     g1.N = channels; g1.bias = M.c1[i].bias; g1.Y = t2; g1.ldy = channels;
     STTS_TRY(launch_conv_gemm(st, g1, EPI_STORE, M.c1[i].npad, n_utt, ml));
-    hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(channels, 32), n_utt), dim3(256), 0, st, t2, channels, channels, s.dev, sty, lds,
-                       M.a2[i].col0, 1e-5f, ss, 2 * channels);
-    hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, channels / 4), dim3(256), 0, st, t2, channels, t1, channels, channels, s.dev, ss,
-                       2 * channels, (int)ACT_NONE, (const float*)M.alpha2[i]);
+    STTS_TRY(run_adain(st, s, t2, channels, channels, t1, channels, sty, lds, M.a2[i].col0, ACT_NONE, M.alpha2[i], ss));
     GemmArgs g2 = gemm_args(s);
     set_seg(g2, 0, t1, channels, 0, M.c2[i]);
     g2.N = channels; g2.bias = M.c2[i].bias; g2.R = cur; g2.ldr = channels;

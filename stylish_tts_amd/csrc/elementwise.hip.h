@@ -32,68 +32,105 @@ __global__ void __launch_bounds__(256) style_fc_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// InstanceNorm statistics folded with the AdaIN affine:  y = x*scale + shift with
-//   scale = rstd*(1+gamma), shift = beta - mean*scale      (models/ada_norm.py:135-139; eps 1e-5, biased var)
-// grid (ceil(C/32), n_utt); block 256 = 8 row lanes x 32 channels; two passes (mean, centred squares).
-// gb = style table row of this utterance: gamma at gcol0 + c, beta at gcol0 + C + c.
+// AdaIN = (1+gamma) * InstanceNorm(x) + beta, per (utterance, channel) over time, eps 1e-5, biased variance
+// (models/ada_norm.py:129-139).  Two launches:
+//  1. adain_partial_kernel: per (utterance, 128-row chunk, 32-channel group) the chunk mean and the centred sum of
+//     squares, from registers (each row read once) - grid (C/32, chunks, n_utt) fills the chip even at B = 1.
+//  2. adain_apply_kernel: each thread owns 4 channels; it merges the chunk statistics (Chan's parallel-variance
+//     update, exact and order-fixed => deterministic), folds them with the style affine into scale/shift and
+//     streams its rows:  y = act(x*scale + shift).   Pad columns C..ldy are written as zeros.
+// part layout: [(u * nchunk + chunk) * 2 + {0: mean, 1: M2}][ldp]
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) adain_stats_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
-                                                          const float* __restrict__ gb, int ld_gb, int gcol0, float eps,
-                                                          float* __restrict__ scale_shift, int ld_ss) {
+constexpr int kStatChunk = 128;
+__global__ void __launch_bounds__(256) adain_partial_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
+                                                            float* __restrict__ part, int ldp, int nchunk) {
   __shared__ float red[8][33];
-  const int u = blockIdx.y;
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int u = blockIdx.z, ch = blockIdx.y;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), cl = threadIdx.x & 31;
   const int rl = threadIdx.x >> 5;
-  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int lo = seg_off[u] + ch * kStatChunk, hi = min(seg_off[u + 1], lo + kStatChunk);
+  if (lo >= hi) return;
   const bool ok = c < C;
+  float v[kStatChunk / 8];
   float acc = 0.f;
-  if (ok)
-    for (int r = lo + rl; r < hi; r += 8) acc += X[(long)r * ldx + c];
-  red[rl][threadIdx.x & 31] = acc;
+#pragma unroll
+  for (int i = 0; i < kStatChunk / 8; ++i) {
+    const int r = lo + rl + 8 * i;
+    v[i] = (ok && r < hi) ? X[(long)r * ldx + c] : 0.f;
+    acc += v[i];
+  }
+  red[rl][cl] = acc;
   __syncthreads();
   float mean = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) mean += red[i][threadIdx.x & 31];
-  const float n = (float)(hi - lo);
-  mean /= n;
+  for (int i = 0; i < 8; ++i) mean += red[i][cl];
+  mean /= (float)(hi - lo);
   __syncthreads();
   acc = 0.f;
-  if (ok)
-    for (int r = lo + rl; r < hi; r += 8) {
-      const float d = X[(long)r * ldx + c] - mean;
+#pragma unroll
+  for (int i = 0; i < kStatChunk / 8; ++i) {
+    const int r = lo + rl + 8 * i;
+    if (r < hi) {
+      const float d = v[i] - mean;
       acc += d * d;
     }
-  red[rl][threadIdx.x & 31] = acc;
+  }
+  red[rl][cl] = acc;
   __syncthreads();
   if (rl == 0 && ok) {
-    float var = 0.f;
+    float m2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) var += red[i][threadIdx.x & 31];
-    var /= n;
-    const float rstd = rsqrtf(var + eps);
-    const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
-    const float sc = rstd * (1.0f + g);
-    scale_shift[(long)u * ld_ss + c] = sc;
-    scale_shift[(long)u * ld_ss + ld_ss / 2 + c] = be - mean * sc;
+    for (int i = 0; i < 8; ++i) m2 += red[i][cl];
+    float* p = part + ((long)(u * nchunk + ch) * 2) * ldp;
+    p[c] = mean;
+    p[ldp + c] = m2;
   }
 }
 
-// y[row][c] = act(x*scale + shift) for c < C, 0 for C <= c < ldy.  grid (row chunks, n_utt).
+// grid (ceil(ldy/64), row blocks of 64, n_utt); block 256 = 16 float4 columns x 16 row lanes.
 // snake: y = v + sin^2(alpha*v)/alpha (AdaptiveGeneratorBlock, models/ada_norm.py:114,117) when alpha != null.
 __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int C,
-                                                          const int* __restrict__ seg_off, const float* __restrict__ scale_shift,
-                                                          int ld_ss, int act, const float* __restrict__ alpha) {
-  const int u = blockIdx.y;
+                                                          const int* __restrict__ seg_off, const float* __restrict__ part, int ldp, int nchunk,
+                                                          const float* __restrict__ gb, int ld_gb, int gcol0, float eps, int act,
+                                                          const float* __restrict__ alpha) {
+  const int u = blockIdx.z;
   const int lo = seg_off[u], hi = seg_off[u + 1];
-  const int nv = ldy / 4;  // float4 per row
-  const long total = (long)(hi - lo) * nv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int r = lo + (int)(i / nv), c4 = (int)(i % nv) * 4;
+  const int r0 = lo + blockIdx.y * 64;
+  if (r0 >= hi) return;
+  const int c4 = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+  if (c4 >= ldy) return;
+  float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f};
+  const float n = (float)(hi - lo);
+  const int nch = (hi - lo + kStatChunk - 1) / kStatChunk;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c4 + k;
+    if (c < C) {
+      float mean = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        const float nc = (float)min(kStatChunk, hi - lo - ch * kStatChunk);
+        mean += nc * part[((long)(u * nchunk + ch) * 2) * ldp + c];
+      }
+      mean /= n;
+      float m2 = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        const float nc = (float)min(kStatChunk, hi - lo - ch * kStatChunk);
+        const float* p = part + ((long)(u * nchunk + ch) * 2) * ldp;
+        const float d = p[c] - mean;
+        m2 += p[ldp + c] + nc * d * d;
+      }
+      const float rstd = rsqrtf(m2 / n + eps);
+      const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
+      sc[k] = rstd * (1.0f + g);
+      sh[k] = be - mean * sc[k];
+      if (alpha) al[k] = alpha[c];
+    }
+  }
+  const int rend = min(hi, r0 + 64);
+  for (int r = r0 + (threadIdx.x >> 4); r < rend; r += 16) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < C) {
       const float4 x = *reinterpret_cast<const float4*>(X + (long)r * ldx + c4);
-      const float* sc = scale_shift + (long)u * ld_ss + c4;
-      const float* sh = sc + ld_ss / 2;
       float xv[4] = {x.x, x.y, x.z, x.w}, ov[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -101,9 +138,8 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
         if (c4 + k < C) {
           v = xv[k] * sc[k] + sh[k];
           if (alpha) {
-            const float al = alpha[c4 + k];
-            const float sn = sinf(al * v);
-            v = v + sn * sn / al;
+            const float sn = sinf(al[k] * v);
+            v = v + sn * sn / al[k];
           } else {
             v = act_apply(v, act);
           }
@@ -241,42 +277,38 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ X
 // partial sums the pwconv1 GEMM epilogue wrote), Nx = Gx / (mean_c Gx + 1e-6).  GRN(U) = U*(gamma*Nx + 1) + beta
 // is folded into pwconv2:  W2_u[co][c] = W2[co][c] * (gamma[c]*Nx[u][c] + 1)   (beta goes into the bias at load).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) grn_scale_kernel(const float* __restrict__ part, int ld_ss, int ss_stride,
-                                                        const int* __restrict__ seg_off, const float* __restrict__ gamma, int C,
-                                                        float* __restrict__ scale, int ld_scale) {
-  __shared__ float red[4];
-  const int u = blockIdx.x;
+// gx[u][c] = sqrt(sum over the utterance's 32-row sub-tiles of the partial sums of squares); grid (ceil(C/256), n_utt)
+__global__ void __launch_bounds__(256) grn_gx_kernel(const float* __restrict__ part, int ld_ss, int ss_stride, const int* __restrict__ seg_off,
+                                                     int C, float* __restrict__ gx, int ld_gx) {
+  const int u = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
   const int nsub = (seg_off[u + 1] - seg_off[u] + 31) / 32;
-  float gsum = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int t = 0; t < nsub; ++t) s += part[((long)u * ss_stride + t) * ld_ss + c];
-    const float g = sqrtf(s);
-    scale[(long)u * ld_scale + c] = g;
-    gsum += g;
-  }
-  gsum = wave_sum(gsum);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsum;
-  __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
-  const float inv = 1.0f / (mean + 1e-6f);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float g = scale[(long)u * ld_scale + c];
-    scale[(long)u * ld_scale + c] = gamma[c] * (g * inv) + 1.0f;
-  }
+  float s = 0.f;
+  for (int t = 0; t < nsub; ++t) s += part[((long)u * ss_stride + t) * ld_ss + c];
+  gx[(long)u * ld_gx + c] = sqrtf(s);
 }
 
-// Wu[u][row][k] = W[row][k] * scale[u][k]   (W packed [Npad][kc], one tap)
-__global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restrict__ W, const float* __restrict__ scale, int ld_scale,
-                                                           float* __restrict__ Wu, int npad, int kc) {
+// Wu[u][row][k] = W[row][k] * (gamma[k] * gx[u][k] / (mean_k gx[u][:] + 1e-6) + 1)   (W packed [Npad][kc], one tap)
+// every block recomputes the channel mean of its utterance (kc values, L2 resident) - no extra launch.
+__global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restrict__ W, const float* __restrict__ gx, int ld_gx,
+                                                           const float* __restrict__ gamma, float* __restrict__ Wu, int npad, int kc) {
+  __shared__ float red[4];
   const int u = blockIdx.y;
+  float part = 0.f;
+  for (int k = threadIdx.x; k < kc; k += 256) part += gx[(long)u * ld_gx + k];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1] + red[2] + red[3]) / (float)kc + 1e-6f);
   const long total4 = (long)npad * kc / 4;
   const int k4n = kc / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     const int k4 = (int)(i % k4n) * 4;
     const float4 w = reinterpret_cast<const float4*>(W)[i];
-    const float4 s = *reinterpret_cast<const float4*>(scale + (long)u * ld_scale + k4);
-    reinterpret_cast<float4*>(Wu + (long)u * npad * kc)[i] = make_float4(w.x * s.x, w.y * s.y, w.z * s.z, w.w * s.w);
+    const float4 g = *reinterpret_cast<const float4*>(gx + (long)u * ld_gx + k4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + k4);
+    reinterpret_cast<float4*>(Wu + (long)u * npad * kc)[i] =
+        make_float4(w.x * (ga.x * g.x * inv + 1.f), w.y * (ga.y * g.y * inv + 1.f), w.z * (ga.z * g.z * inv + 1.f), w.w * (ga.w * g.w * inv + 1.f));
   }
 }
 
@@ -410,6 +442,34 @@ __global__ void __launch_bounds__(256) to_channel_major_kernel(const float* __re
     const int c = c0 + i, t = t0 + tx;
     if (c < C && t < T) Y[((long)b * C + c) * T + t] = tile[tx][i];
   }
+}
+
+// One extra output channel of a Conv1d as a dot product per row (one wave per row).  Used for the Nyquist bin of the
+// vocoder's output convs: 1025 = 8 x 128 + 1 output channels, so the GEMM computes 1024 of them with full tiles and
+// this kernel the last one (generator.py:344-358).  w is tap-major [ntaps][C].
+__global__ void __launch_bounds__(256) single_channel_conv_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
+                                                                  const int* __restrict__ row_utt, const float* __restrict__ w, float bias,
+                                                                  int ntaps, float* __restrict__ Y, int ldy, int ycol, int n_rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int u = row_utt[row];
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int pad = (ntaps - 1) / 2, nv = C / 4;
+  float acc = 0.f;
+  for (int t = 0; t < ntaps; ++t) {
+    const int g = row + t - pad;
+    if (g < lo || g >= hi) continue;
+    const float* x = X + (long)g * ldx;
+    const float* wt = w + (long)t * C;
+    for (int q = lane; q < nv; q += 64) {
+      const float4 a = *reinterpret_cast<const float4*>(x + q * 4);
+      const float4 b = *reinterpret_cast<const float4*>(wt + q * 4);
+      acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) Y[(long)row * ldy + ycol] = acc + bias;
 }
 
 __global__ void fill_kernel(float* p, long n, float v) {

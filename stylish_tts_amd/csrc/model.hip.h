@@ -106,7 +106,9 @@ struct stts_ctx {
   stts::FlowLayerW flow[8];
   stts::StyleTable flow_style;
   // generator
-  stts::PackedConv amp_prior, phase_prior, proj_mel, proj_la, proj_ph, amp_out, phase_out;
+  stts::PackedConv amp_prior, phase_prior, proj_mel, proj_la, proj_ph, amp_out, phase_out;  // *_out: the first n_fft/2 channels
+  float* nyq_w[2] = {nullptr, nullptr};  // last (Nyquist) output channel of amp/phase output convs, [taps][cin]
+  float nyq_b[2] = {0.f, 0.f};
   stts::ConvNextW cnx[4];
   stts::StyleSlot head_amp, head_phase;
   stts::StyleTable gen_style;
@@ -350,8 +352,21 @@ inline int finalize_frame(stts_ctx* c) {
     STTS_TRY(pack_plain(c, g + "projector", true, 0, d.gen_input, &c->proj_mel));
     STTS_TRY(pack_plain(c, g + "projector", false, d.gen_input, hp, &c->proj_la));
     STTS_TRY(pack_plain(c, g + "projector", false, d.gen_input + hp, hp, &c->proj_ph));
-    STTS_TRY(pack_plain(c, g + "amp_output_conv", true, 0, h + hp, &c->amp_out));
-    STTS_TRY(pack_plain(c, g + "phase_output_conv", true, 0, h + hp, &c->phase_out));
+    // output convs: n_fft/2 + 1 = 8*128 + 1 channels -> GEMM for the first 1024, a dot-product kernel for the last
+    for (int which = 0; which < 2; ++which) {
+      const std::string nm = g + (which == 0 ? "amp_output_conv" : "phase_output_conv");
+      HostTensor w;
+      STTS_TRY(get_weight(c, nm, &w));
+      STTS_GET(b, nm + ".bias");
+      const int nmain = kBins - 1, ci = (int)w.shape[1], kk = (int)w.shape[2];
+      STTS_CHECK((int)w.shape[0] == kBins && ci == h + hp, "%s: unexpected shape", nm.c_str());
+      STTS_TRY(pack_rows(c, w, b, plain_rows(nmain), 0, ci, round_up(ci, 32), nmain, which == 0 ? &c->amp_out : &c->phase_out));
+      std::vector<float> last((size_t)kk * ci);
+      for (int t = 0; t < kk; ++t)
+        for (int q = 0; q < ci; ++q) last[(size_t)t * ci + q] = w.data[((size_t)nmain * ci + q) * kk + t];
+      STTS_TRY(dev_upload(c, last, &c->nyq_w[which]));
+      c->nyq_b[which] = b->data[nmain];
+    }
     const int ks[4] = {31, 15, 7, 3};
     for (int i = 0; i < 4; ++i) {
       const std::string q = g + "convnext." + std::to_string(i) + ".";
@@ -459,18 +474,27 @@ inline dim3 rows_grid(const Seg& s, int per_row_work) {
   return dim3((unsigned)std::min<long>(std::max<long>(1, ceil_div((int)std::min<long>(total, 1 << 30), 256)), 512), s.n_utt);
 }
 
+// AdaIN + activation: Y[:, :ldy] = act((1+gamma) * InstanceNorm(X[:, :C]) + beta), zeros in the pad columns.
+// part: scratch of adain_part_floats(s, C) floats.
+inline size_t adain_part_floats(const Seg& s, int C) { return (size_t)s.n_utt * ceil_div(s.max_len(), kStatChunk) * 2 * round_up(C, 32); }
+inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int C, float* Y, int ldy, const float* style_out, int ld_style,
+                     int gcol0, int act, const float* alpha, float* part) {
+  const int nchunk = ceil_div(s.max_len(), kStatChunk), ldp = round_up(C, 32);
+  hipLaunchKernelGGL(adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), 0, st, X, ldx, C, s.dev, part, ldp, nchunk);
+  hipLaunchKernelGGL(adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), 64), s.n_utt), dim3(256), 0, st, X, ldx, Y, ldy, C, s.dev,
+                     part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha);
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
 // AdaptiveDecoderBlock (models/ada_norm.py:166-182).  x [rows, ldx] (cols >= cin may hold anything when
 // kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
-// scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [n_utt, 2*max(kcin,cout)]
+// scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [adain_part_floats(s, max(kcin, cout))]
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
                            float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0) {
-  const int ldss = 2 * std::max(B.kcin, B.cout);
   const int ml = s.max_len();
   // norm1 -> LeakyReLU
-  hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(B.cin, 32), s.n_utt), dim3(256), 0, st, x, ldx, B.cin, s.dev, style_out, ld_style,
-                     B.n1.col0, 1e-5f, ss, ldss);
-  hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, B.kcin / 4), dim3(256), 0, st, x, ldx, act1, B.kcin, B.cin, s.dev, ss, ldss,
-                     (int)ACT_LRELU, (const float*)nullptr);
+  STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ss));
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, act1, B.kcin, 0, B.conv1);
   a.N = B.cout;
@@ -479,10 +503,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   a.ldy = B.cout;
   STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
   // norm2 -> LeakyReLU
-  hipLaunchKernelGGL(adain_stats_kernel, dim3(ceil_div(B.cout, 32), s.n_utt), dim3(256), 0, st, hbuf, B.cout, B.cout, s.dev, style_out,
-                     ld_style, B.n2.col0, 1e-5f, ss, ldss);
-  hipLaunchKernelGGL(adain_apply_kernel, rows_grid(s, B.cout / 4), dim3(256), 0, st, hbuf, B.cout, act2, B.cout, B.cout, s.dev, ss, ldss,
-                     (int)ACT_LRELU, (const float*)nullptr);
+  STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, ss));
   // conv2 (+ learned 1x1 shortcut as a second K segment | + identity residual), / sqrt(2)
   GemmArgs b = gemm_args(s);
   set_seg(b, 0, act2, B.cout, 0, B.conv2);
@@ -517,7 +538,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* act1 = ws.get<float>(R * ldcat);
   float* hbuf = ws.get<float>(R * d.dec_hidden);
   float* act2 = ws.get<float>(R * d.dec_hidden);
-  float* ss = ws.get<float>((size_t)s.n_utt * 2 * ldcat);
+  float* ss = ws.get<float>(adain_part_floats(s, ldcat));
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
@@ -705,8 +726,8 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     a.N = inter; a.bias = B.pw1.bias; a.Y = U; a.ldy = inter; a.act = ACT_SILU;
     a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
-    hipLaunchKernelGGL(grn_scale_kernel, dim3(s.n_utt), dim3(256), 0, st, part, inter, ss_stride, s.dev, B.grn_gamma, inter, gscale, inter);
-    hipLaunchKernelGGL(scale_weight_kernel, dim3(256, s.n_utt), dim3(256), 0, st, B.pw2.W, gscale, inter, w2u, B.pw2.npad, B.pw2.kc);
+    hipLaunchKernelGGL(grn_gx_kernel, dim3(ceil_div(inter, 256), s.n_utt), dim3(256), 0, st, part, inter, ss_stride, s.dev, inter, gscale, inter);
+    hipLaunchKernelGGL(scale_weight_kernel, dim3(128, s.n_utt), dim3(256), 0, st, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, U, inter, 0, B.pw2);
     b.seg[0].W = w2u;
@@ -723,12 +744,17 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   {
     GemmArgs a = gemm_args(s);
     set_seg(a, 0, headA, hc, 0, c->amp_out);
-    a.N = kBins; a.bias = c->amp_out.bias; a.Y = la; a.ldy = ldl;
+    a.N = kBins - 1; a.bias = c->amp_out.bias; a.Y = la; a.ldy = ldl;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->amp_out.npad, s.n_utt, ml));
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, headP, hc, 0, c->phase_out);
-    b.N = kBins; b.bias = c->phase_out.bias; b.Y = ph; b.ldy = ldl;
+    b.N = kBins - 1; b.bias = c->phase_out.bias; b.Y = ph; b.ldy = ldl;
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
+    const int kk = c->amp_out.ntaps;
+    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), 0, st, headA, hc, hc, s.dev, row_utt, c->nyq_w[0],
+                       c->nyq_b[0], kk, la, ldl, kBins - 1, (int)R);
+    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), 0, st, headP, hc, hc, s.dev, row_utt, c->nyq_w[1],
+                       c->nyq_b[1], kk, ph, ldl, kBins - 1, (int)R);
   }
   hipLaunchKernelGGL(istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), 0, st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
   hipLaunchKernelGGL(istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), 0, st, yw, s.dev, c->hann, audio);
