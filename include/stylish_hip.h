@@ -98,6 +98,33 @@ int stts_frame_path(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_o
                     const float* prior_noise, const float* src_noise, const float* init_phase, int batch_scope,
                     float* audio_out, void* ws, size_t ws_bytes);
 
+/* ---- phoneme-rate predictors.  Sequences are packed: tok_off[n_utt+1] token offsets, tokens int64 [n_tok]. ---- */
+size_t stts_phoneme_workspace_bytes(const stts_ctx* ctx, int64_t n_tokens, int64_t n_frames, int n_utt);
+
+/* TextEncoder.forward (models/text_encoder.py:433-462).  which: 0 duration_predictor.text_encoder,
+ * 1 speech_predictor.text_encoder, 2 pe_text_encoder.  -> mu [n_tok, ld_mu >= inter_dim] (proj_m), optional x [n_tok, 128]. */
+int stts_text_encoder_forward(stts_ctx* ctx, void* stream, int which, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
+                              const int64_t* tokens, float* mu_out, int ld_mu, float* x_out, void* ws, size_t ws_bytes);
+/* TextStyleEncoder.forward (models/text_style_encoder.py:20-26; BasicConvNeXtBlock models/conv_next.py:38-51).
+ * which as above (0 duration_predictor.style_encoder, 1 speech_predictor.style_encoder, 2 pe_text_style_encoder).
+ * x [n_tok, ldx] -> style [n_utt, 64].  Statistics are per utterance over its own tokens (the reference at B = 1). */
+int stts_text_style_forward(stts_ctx* ctx, void* stream, int which, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
+                            const float* x, int ldx, float* style_out, void* ws, size_t ws_bytes);
+/* DurationPredictor.forward (models/duration_predictor.py:30-36) -> logits [n_tok, 16]; optional
+ * DurationProcessor.prediction_to_duration (train/utils.py:468-474) -> dur int32 [n_tok]; optional taps
+ * text_encoder mu [n_tok,128], style [n_utt,64], prosody [n_tok,192]. */
+int stts_duration_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
+                          const int64_t* tokens, float* logits_out, int32_t* dur_out, float* mu_out, float* style_out, float* prosody_out,
+                          void* ws, size_t ws_bytes);
+/* PitchEnergyPredictor.forward (models/pitch_energy_predictor.py:104-121) incl. compute_cross (:83-102) with the
+ * reference's inverted band mask (:194-212 vs models/text_encoder.py:255-262).  The alignment is given as integer
+ * durations (train/utils.py:476-489).  pe_enc [n_tok, ld_enc >= 256], pe_style [n_utt,64] -> f0, energy [n_frames]
+ * at the mel-frame rate; optional taps prosody [n_tok,320], cross [n_frames,320]. */
+int stts_pitch_energy_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
+                              const int32_t* frm_off_host, const int32_t* frm_off_dev, const int32_t* dur, const float* pe_enc, int ld_enc,
+                              const float* pe_style, float* f0_out, float* energy_out, float* prosody_out, float* cross_out, void* ws,
+                              size_t ws_bytes);
+
 /* Length regulator (train/utils.py:476-489 + models/speech_predictor.py:88-93): integer durations per token ->
  * time-major gather of the phoneme encoding at rate rep (1: mel frames, 4: vocoder frames).
  * dur [n_tok] int32 (device), tok_off [n_utt+1], frm_off [n_utt+1] (= rep * cumulative durations), both device.

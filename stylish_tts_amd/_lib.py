@@ -59,6 +59,11 @@ SIGNATURES = {
     "stts_harmonic_stft": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _SZ]),
     "stts_vocoder_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _SZ]),
     "stts_frame_path": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ]),
+    "stts_phoneme_workspace_bytes": (_SZ, [_P, _I64, _I64, _I]),
+    "stts_text_encoder_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _SZ]),
+    "stts_text_style_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _SZ]),
+    "stts_duration_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ]),
+    "stts_pitch_energy_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _SZ]),
     "stts_length_regulate": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I, _P, _I, _I, _P, _I, _P]),
     "stts_upsample4": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "stts_to_time_major": (_I, [_P, _P, _I, _I, _I, _P, _I]),

@@ -64,6 +64,12 @@ int stts_finalize_weights(stts_ctx* c, int which) {
   STTS_CHECK(c, "null ctx");
   STTS_HIP(hipSetDevice(c->device));
   if (which & 1) STTS_TRY(finalize_frame(c));
+  if (which & 2) {
+    auto m = std::make_shared<PhonemeModel>();
+    STTS_TRY(finalize_phoneme(c, m.get()));
+    c->phoneme = m;
+    c->phoneme_ready = true;
+  }
   STTS_HIP(hipDeviceSynchronize());
   return 0;
   API_END
@@ -76,6 +82,7 @@ int stts_check_status(stts_ctx* c, void* stream) {
   STTS_HIP(hipMemcpy(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (e) {
     STTS_HIP(hipMemset(c->d_err, 0, sizeof(int)));
+    if (e == 2) return stts::fail("text encoder: token id outside [0, tokens)");
     return stts::fail("harmonic source: a frame is voiced (f0 > 10 Hz) but no f0 exceeds 20 Hz (reference raises: models/generator.py:285)");
   }
   return 0;
@@ -187,6 +194,74 @@ int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, i
   hipLaunchKernelGGL(to_channel_major_kernel, dim3(ceil_div(T, 32), ceil_div(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, 0, B, C, T, y);
   STTS_HIP(hipGetLastError());
   return 0;
+  API_END
+}
+
+// ------------------------------------------------------------------------------------------------ phoneme-rate stages
+#define PH_CHECK()                                                                   \
+  STTS_CHECK(c && c->phoneme_ready, "phoneme-rate weights not finalized (stts_finalize_weights which & 2)"); \
+  PhonemeModel& M = *static_cast<PhonemeModel*>(c->phoneme.get());                   \
+  hipStream_t st = (hipStream_t)stream
+
+static int seg_ok(int n_utt, const int32_t* h, const int32_t* d) {
+  STTS_CHECK(n_utt > 0 && h && d && h[0] == 0, "bad utterance offsets");
+  for (int u = 0; u < n_utt; ++u) STTS_CHECK(h[u + 1] > h[u], "utterance %d is empty", u);
+  return 0;
+}
+
+size_t stts_phoneme_workspace_bytes(const stts_ctx* c, int64_t n_tokens, int64_t n_frames, int n_utt) {
+  return phoneme_workspace_bytes(c, n_tokens, n_frames, n_utt);
+}
+
+int stts_text_encoder_forward(stts_ctx* c, void* stream, int which, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
+                              const int64_t* tokens, float* mu_out, int ld_mu, float* x_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  PH_CHECK();
+  STTS_CHECK(which >= 0 && which < 3, "which must be 0 (duration), 1 (speech) or 2 (pitch/energy)");
+  STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
+  STTS_CHECK(ld_mu >= M.te[which].inter, "ld_mu too small");
+  Seg s{n_utt, tok_off_host, tok_off_dev};
+  Arena a(ws, ws_bytes);
+  return text_encoder_forward(c, st, M.te[which], s, (const long*)tokens, mu_out, ld_mu, x_out, a);
+  API_END
+}
+
+int stts_text_style_forward(stts_ctx* c, void* stream, int which, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev, const float* x,
+                            int ldx, float* style_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  PH_CHECK();
+  STTS_CHECK(which >= 0 && which < 3, "which must be 0, 1 or 2");
+  STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
+  STTS_CHECK(ldx % 32 == 0 && ldx >= M.se[which].inter, "style encoder input: ld must be a multiple of 32 covering inter_dim");
+  Seg s{n_utt, tok_off_host, tok_off_dev};
+  Arena a(ws, ws_bytes);
+  return text_style_forward(c, st, M.se[which], s, x, ldx, style_out, c->d.style_dim, a);
+  API_END
+}
+
+int stts_duration_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev, const int64_t* tokens,
+                          float* logits_out, int32_t* dur_out, float* mu_out, float* style_out, float* prosody_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  PH_CHECK();
+  STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
+  Seg s{n_utt, tok_off_host, tok_off_dev};
+  Arena a(ws, ws_bytes);
+  return duration_forward(c, M, st, s, (const long*)tokens, logits_out, 16, dur_out, mu_out, style_out, prosody_out, a);
+  API_END
+}
+
+int stts_pitch_energy_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
+                              const int32_t* frm_off_host, const int32_t* frm_off_dev, const int32_t* dur, const float* pe_enc, int ld_enc,
+                              const float* pe_style, float* f0_out, float* energy_out, float* prosody_out, float* cross_out, void* ws,
+                              size_t ws_bytes) {
+  API_BEGIN
+  PH_CHECK();
+  STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
+  STTS_TRY(seg_ok(n_utt, frm_off_host, frm_off_dev));
+  STTS_CHECK(ld_enc >= c->d.pe_inter && ld_enc % 4 == 0, "bad ld_enc");
+  Seg sp{n_utt, tok_off_host, tok_off_dev}, sf{n_utt, frm_off_host, frm_off_dev};
+  Arena a(ws, ws_bytes);
+  return pitch_energy_forward(c, M, st, sp, sf, dur, pe_enc, ld_enc, pe_style, f0_out, energy_out, prosody_out, cross_out, a);
   API_END
 }
 

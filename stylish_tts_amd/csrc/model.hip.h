@@ -12,6 +12,7 @@
 #include "elementwise.hip.h"
 #include "gemm.hip.h"
 #include "signal.hip.h"
+#include "phoneme.hip.h"
 
 namespace stts {
 
@@ -116,6 +117,8 @@ struct stts_ctx {
   std::map<std::string, std::unique_ptr<stts::AdainBlockW>> op_blocks;
   std::map<std::string, std::unique_ptr<stts::StyleTable>> op_tables;
   std::map<std::string, std::unique_ptr<stts::MrfW>> op_mrf;
+  std::shared_ptr<void> phoneme;  // stts::PhonemeModel (phoneme_model.hip.h)
+  bool phoneme_ready = false;
 };
 
 namespace stts {
@@ -799,3 +802,5 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
 }
 
 }  // namespace stts
+
+#include "phoneme_model.hip.h"

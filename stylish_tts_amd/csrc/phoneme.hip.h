@@ -1,0 +1,167 @@
+// Phoneme-rate kernels: embedding, rotary position embedding, multi-head attention,
+// style broadcast / masked mean, duration decoding.  Sequences are short (P <= 512 tokens, T <= ~1000 frames),
+// so these kernels are written for exactness and low launch count, not for bandwidth: each is a tiny fraction of
+// the step (the phoneme-rate part is ~3 % of the FLOPs).
+#pragma once
+#include "common.h"
+
+namespace stts {
+
+// x[row][:] = emb[token[row]][:] * sqrt(C)          (models/text_encoder.py:451)
+__global__ void __launch_bounds__(256) embed_kernel(const long* __restrict__ tokens, const float* __restrict__ emb, int C, int n_tokens_vocab,
+                                                    float scale, float* __restrict__ Y, int ldy, int n_rows, int* __restrict__ err) {
+  const int nv = C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)n_rows * nv; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / nv), c4 = (int)(i % nv) * 4;
+    long t = tokens[r];
+    if (t < 0 || t >= n_tokens_vocab) {
+      atomicExch(err, 2);
+      t = 0;
+    }
+    const float4 e = *reinterpret_cast<const float4*>(emb + t * C + c4);
+    *reinterpret_cast<float4*>(Y + (long)r * ldy + c4) = make_float4(e.x * scale, e.y * scale, e.z * scale, e.w * scale);
+  }
+}
+
+// Rotary position embedding in place on the first d features of every head (RotaryPositionalEmbeddings.forward,
+// models/text_encoder.py:146-168; d = int(k_channels * 0.5), text_encoder.py:194-195):
+//   j <  d/2: x_j' = x_j cos(p th_j) - x_{j+d/2} sin(p th_j)
+//   j >= d/2: x_j' = x_j cos(p th_{j-d/2}) + x_{j-d/2} sin(p th_{j-d/2}),   th_i = 10000^(-2i/d), p = position in the utterance
+// grid (row chunks, n_utt); thread per (row, head, pair).
+__global__ void __launch_bounds__(256) rope_kernel(float* __restrict__ X, int ldx, int col0, int n_heads, int kc, int d,
+                                                   const int* __restrict__ seg_off) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], n = seg_off[u + 1] - lo;
+  const int half = d / 2;
+  const long total = (long)n * n_heads * half;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int j = (int)(i % half);
+    const int h = (int)((i / half) % n_heads);
+    const int p = (int)(i / ((long)half * n_heads));
+    const float theta = 1.0f / powf(10000.0f, (float)(2 * j) / (float)d);
+    const float ang = (float)p * theta;
+    const float cs = cosf(ang), sn = sinf(ang);
+    float* x = X + (long)(lo + p) * ldx + col0 + h * kc;
+    const float a = x[j], b = x[j + half];
+    x[j] = a * cs - b * sn;
+    x[j + half] = b * cs + a * sn;
+  }
+}
+
+// Multi-head scaled-dot-product attention (MultiHeadAttention.attention, models/text_encoder.py:233-277) on packed
+// sequences: queries of utterance u attend to the keys of utterance u only (the reference's padding mask fills -1e4,
+// whose softmax weight underflows to exactly 0 in fp32, so dropping padded keys is identical).
+// One wave per (query row, head).  Phase 1: lanes <-> keys, scores into LDS; phase 2: lanes <-> channels.
+// band (cross-attention of the pitch/energy predictor): the reference builds "True = NOT allowed" but the attention fills
+// -1e4 where its mask is FALSE (pitch_energy_predictor.py:194-212 vs text_encoder.py:255-262), so scores are lowered by
+// 1e4 INSIDE |key - centre[query]| <= window and untouched outside.  Reproduced as is.
+constexpr int kAttnMaxKeys = 1024, kAttnMaxKc = 192;
+__global__ void __launch_bounds__(256) attention_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
+                                                        int kcol0, const float* __restrict__ V, int ldv, int vcol0, float* __restrict__ O, int ldo,
+                                                        int n_heads, int kc, const int* __restrict__ q_off, const int* __restrict__ k_off,
+                                                        const int* __restrict__ band_centre, int window, float scale) {
+  __shared__ float sq[4][kAttnMaxKc];
+  __shared__ float sp[4][kAttnMaxKeys];
+  const int u = blockIdx.z, h = blockIdx.y;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qlo = q_off[u], nq = q_off[u + 1] - qlo;
+  const int klo = k_off[u], nk = k_off[u + 1] - klo;
+  const int qi = blockIdx.x * 4 + w;
+  if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
+  const float* q = Q + (long)(qlo + qi) * ldq + qcol0 + h * kc;
+  for (int c = lane; c < kc; c += 64) sq[w][c] = q[c];
+  __builtin_amdgcn_wave_barrier();
+  const int centre = band_centre ? band_centre[qlo + qi] : 0;
+  float mx = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
+    const float* kr = K + (long)(klo + j) * ldk + kcol0 + h * kc;
+    float s = 0.f;
+    for (int c = 0; c < kc; c += 4) {
+      const float4 kv = *reinterpret_cast<const float4*>(kr + c);
+      s += sq[w][c] * kv.x + sq[w][c + 1] * kv.y + sq[w][c + 2] * kv.z + sq[w][c + 3] * kv.w;
+    }
+    s *= scale;
+    if (band_centre && j >= centre - window && j <= centre + window) s += -1e4f;
+    sp[w][j] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    const float e = expf(sp[w][j] - mx);
+    sp[w][j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  const float inv = 1.0f / sum;
+  float* o = O + (long)(qlo + qi) * ldo + h * kc;
+  for (int c = lane; c < kc; c += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < nk; ++j) acc += sp[w][j] * V[(long)(klo + j) * ldv + vcol0 + h * kc + c];
+    o[c] = acc * inv;
+  }
+}
+
+// Y[row][col0 + c] = style[u][c] for every row of utterance u (ProsodyEncoder concat, models/prosody_encoder.py:67-69,80)
+__global__ void __launch_bounds__(256) broadcast_style_kernel(const float* __restrict__ style, int ld_style, int C, float* __restrict__ Y, int ldy,
+                                                              int col0, const int* __restrict__ seg_off) {
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], n = seg_off[u + 1] - lo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)n * C; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / C), c = (int)(i % C);
+    Y[(long)(lo + r) * ldy + col0 + c] = style[(long)u * ld_style + c];
+  }
+}
+
+// style[u][c] = mean over the utterance's rows of X[:, c]     (TextStyleEncoder masked mean, text_style_encoder.py:24-26)
+__global__ void __launch_bounds__(256) mean_rows_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
+                                                        float* __restrict__ out, int ld_out) {
+  const int u = blockIdx.x;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int r = lo; r < hi; ++r) s += X[(long)r * ldx + c];
+    out[(long)u * ld_out + c] = s / (float)(hi - lo);
+  }
+}
+
+// DurationProcessor.prediction_to_duration (train/utils.py:468-474): softmax . class table summed, round (half to
+// even), clamp >= 1; argmax -> table; hard if hard < 7 else soft.  One thread per token; 16 classes.
+__constant__ float kClassToDur[16] = {1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46};
+__global__ void __launch_bounds__(256) duration_decode_kernel(const float* __restrict__ logits, int ld, int n_classes, int n_rows,
+                                                              int* __restrict__ dur) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const float* l = logits + (long)r * ld;
+  float mx = l[0];
+  int am = 0;
+  for (int k = 1; k < n_classes; ++k)
+    if (l[k] > mx) {
+      mx = l[k];
+      am = k;
+    }
+  float den = 0.f;
+  float e[16];
+  for (int k = 0; k < n_classes; ++k) {
+    e[k] = expf(l[k] - mx);
+    den += e[k];
+  }
+  float soft = 0.f;
+  for (int k = 0; k < n_classes; ++k) soft += (e[k] / den) * kClassToDur[k];
+  soft = fmaxf(rintf(soft), 1.0f);
+  const float hard = kClassToDur[am];
+  dur[r] = (int)(hard < 7.0f ? hard : soft);
+}
+
+// token-local index of the token each frame belongs to (build_monotonic_band_mask's tau = alignment.argmax(dim=1),
+// pitch_energy_predictor.py:201)
+__global__ void __launch_bounds__(256) local_token_kernel(const int* __restrict__ src_row, const int* __restrict__ frm_off,
+                                                          const int* __restrict__ tok_off, int* __restrict__ centre) {
+  const int u = blockIdx.y;
+  const int lo = frm_off[u], hi = frm_off[u + 1];
+  for (int f = lo + blockIdx.x * 256 + threadIdx.x; f < hi; f += gridDim.x * 256) centre[f] = src_row[f] - tok_off[u];
+}
+
+}  // namespace stts

@@ -185,3 +185,66 @@ class HipModel:
         _lib.check(self.lib.stts_op_mrf_block(self.ctx, _stream(), prefix.encode(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], channels,
                                               kernel, _ptr(style), _ptr(y), channels, _ptr(ws), ws.numel()))
         return y
+
+    # ------------------------------------------------------------------ phoneme-rate stages (packed tokens)
+    def _ph_ws(self, n_tok: int, n_frames: int, n_utt: int) -> torch.Tensor:
+        need = int(self.lib.stts_phoneme_workspace_bytes(self.ctx, n_tok, n_frames, n_utt))
+        if getattr(self, "_pws", None) is None or self._pws.numel() < need:
+            self._pws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._pws
+
+    def text_encoder(self, which: int, seg: Segments, tokens: torch.Tensor, return_hidden=False):
+        """tokens int64 [n_tok] (packed) -> mu [n_tok, inter] (+ last hidden [n_tok, 128])."""
+        inter = self.cfg.pitch_energy_predictor.inter_dim if which == 2 else self.cfg.inter_dim
+        mu = self._f32(seg.rows, inter)
+        xh = self._f32(seg.rows, self.cfg.text_encoder.hidden_dim) if return_hidden else None
+        ws = self._ph_ws(seg.rows, 0, seg.n)
+        _lib.check(self.lib.stts_text_encoder_forward(self.ctx, _stream(), which, seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(tokens), _ptr(mu), inter,
+                                                      _ptr(xh), _ptr(ws), ws.numel()))
+        return (mu, xh) if return_hidden else mu
+
+    def text_style(self, which: int, seg: Segments, x: torch.Tensor):
+        style = self._f32(seg.n, self.cfg.style_dim)
+        ws = self._ph_ws(seg.rows, 0, seg.n)
+        _lib.check(self.lib.stts_text_style_forward(self.ctx, _stream(), which, seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], _ptr(style),
+                                                    _ptr(ws), ws.numel()))
+        return style
+
+    def duration(self, seg: Segments, tokens: torch.Tensor, taps=False):
+        """-> logits [n_tok,16], dur int32 [n_tok] (+ dict of taps)."""
+        logits = self._f32(seg.rows, 16)
+        dur = torch.empty(seg.rows, dtype=torch.int32, device=self.device)
+        t = None
+        if taps:
+            t = dict(text_mu=self._f32(seg.rows, self.cfg.inter_dim), style=self._f32(seg.n, self.cfg.style_dim),
+                     prosody=self._f32(seg.rows, self.cfg.inter_dim + self.cfg.style_dim))
+        ws = self._ph_ws(seg.rows, 0, seg.n)
+        _lib.check(self.lib.stts_duration_forward(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(tokens), _ptr(logits), _ptr(dur),
+                                                  _ptr(t["text_mu"]) if t else None, _ptr(t["style"]) if t else None,
+                                                  _ptr(t["prosody"]) if t else None, _ptr(ws), ws.numel()))
+        return (logits, dur, t) if taps else (logits, dur)
+
+    def pitch_energy(self, seg_p: Segments, seg_t: Segments, dur: torch.Tensor, pe_enc: torch.Tensor, pe_style: torch.Tensor, taps=False):
+        """dur int32 [n_tok]; -> f0, energy [n_frames] at the mel-frame rate."""
+        f0 = self._f32(seg_t.rows)
+        en = self._f32(seg_t.rows)
+        C = self.cfg.pitch_energy_predictor.inter_dim + self.cfg.style_dim
+        t = dict(prosody=self._f32(seg_p.rows, C), cross=self._f32(seg_t.rows, C)) if taps else None
+        ws = self._ph_ws(seg_p.rows, seg_t.rows, seg_p.n)
+        _lib.check(self.lib.stts_pitch_energy_forward(self.ctx, _stream(), seg_p.n, seg_p.host_ptr, _ptr(seg_p.dev), seg_t.host_ptr, _ptr(seg_t.dev),
+                                                      _ptr(dur), _ptr(pe_enc), pe_enc.shape[1], _ptr(pe_style), _ptr(f0), _ptr(en),
+                                                      _ptr(t["prosody"]) if t else None, _ptr(t["cross"]) if t else None, _ptr(ws), ws.numel()))
+        return (f0, en, t) if taps else (f0, en)
+
+    def length_regulate(self, seg_p: Segments, seg_f: Segments, dur: torch.Tensor, rep: int, enc: torch.Tensor, C: int):
+        """enc [n_tok, ld] -> [n_frames, C] rows gathered by the duration alignment at rate rep (1 or 4)."""
+        out = self._f32(seg_f.rows, C)
+        idx = torch.empty(seg_f.rows, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.stts_length_regulate(self.ctx, _stream(), seg_p.n, _ptr(dur), _ptr(seg_p.dev), _ptr(seg_f.dev), seg_f.rows, rep, _ptr(enc),
+                                                 enc.shape[1], C, _ptr(out), C, _ptr(idx)))
+        return out
+
+    def upsample4(self, seg_t: Segments, seg_t4: Segments, x: torch.Tensor):
+        y = self._f32(seg_t4.rows)
+        _lib.check(self.lib.stts_upsample4(self.ctx, _stream(), seg_t.n, seg_t.host_ptr, _ptr(seg_t.dev), _ptr(seg_t4.dev), _ptr(x), _ptr(y)))
+        return y
