@@ -93,7 +93,7 @@ def main():
     if world > 1:
         sd = broadcast_state_dict(sd, spec, device, src=0)  # RCCL broadcast of the weights, once
     model = HipModel(cfg, local)
-    model.load_weights({"speech_predictor": sd}, which=1)
+    model.load_weights({"speech_predictor": sd}, which=7)
 
     seg = Segments([T4] * BATCH, device)
     inp = synth_inputs(rank, device)

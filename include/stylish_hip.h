@@ -50,8 +50,20 @@ int stts_ctx_create(const stts_model_dims* dims, int device, stts_ctx** out);
 void stts_ctx_destroy(stts_ctx* ctx);
 int stts_load_weight(stts_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
 /* Fold weight-norm (w = g*v/||v||), re-lay out every conv/linear as W[cout][tap][cin] padded for the MFMA
- * tiles, upload.  which: bit 0 frame-rate path (speech_predictor.{decoder,prior_encoder,flow,post_flow,generator}),
- * bit 1 phoneme-rate predictors (text encoders, style encoders, duration, pitch/energy). */
+ * tiles, upload.  `which` is a bit mask of the components whose weights have been loaded (one per reference
+ * sub-module, so that a single module can be dropped in on its own): */
+enum {
+  STTS_W_DECODER = 1,        /* speech_predictor.decoder                                   models/decoder.py */
+  STTS_W_FLOW = 2,           /* speech_predictor.{prior_encoder, flow, post_flow}          models/flow.py */
+  STTS_W_GENERATOR = 4,      /* speech_predictor.generator                                 models/generator.py */
+  STTS_W_SPEECH_TEXT = 8,    /* speech_predictor.{text_encoder, style_encoder}             models/speech_predictor.py:17-25 */
+  STTS_W_DURATION = 16,      /* duration_predictor.*                                       models/duration_predictor.py */
+  STTS_W_PE_TEXT = 32,       /* pe_text_encoder                                            models/models.py:49-52 */
+  STTS_W_PE_STYLE = 64,      /* pe_text_style_encoder                                      models/models.py:53-57 */
+  STTS_W_PITCH_ENERGY = 128, /* pitch_energy_predictor.*                                   models/pitch_energy_predictor.py */
+  STTS_W_FRAME_PATH = 7,
+  STTS_W_ALL = 255
+};
 int stts_finalize_weights(stts_ctx* ctx, int which);
 /* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz
  * (the reference raises there, models/generator.py:285).  Synchronises the stream. */
@@ -124,6 +136,11 @@ int stts_pitch_energy_forward(stts_ctx* ctx, void* stream, int n_utt, const int3
                               const int32_t* frm_off_host, const int32_t* frm_off_dev, const int32_t* dur, const float* pe_enc, int ld_enc,
                               const float* pe_style, float* f0_out, float* energy_out, float* prosody_out, float* cross_out, void* ws,
                               size_t ws_bytes);
+
+/* DurationProcessor.prediction_to_duration (train/utils.py:468-474): logits [n_rows, ld >= 16] -> int32 durations. */
+int stts_duration_decode(void* stream, const float* logits, int ld, int n_rows, int32_t* dur_out);
+/* DurationProcessor.duration_to_alignment (train/utils.py:476-489): durations [P] -> 0/1 matrix [P, T = sum(dur)]. */
+int stts_duration_to_alignment(void* stream, const int32_t* dur, int n_tokens, int n_frames, float* alignment_out);
 
 /* Length regulator (train/utils.py:476-489 + models/speech_predictor.py:88-93): integer durations per token ->
  * time-major gather of the phoneme encoding at rate rep (1: mel frames, 4: vocoder frames).

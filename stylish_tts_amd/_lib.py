@@ -64,6 +64,8 @@ SIGNATURES = {
     "stts_text_style_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _SZ]),
     "stts_duration_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ]),
     "stts_pitch_energy_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _SZ]),
+    "stts_duration_decode": (_I, [_P, _P, _I, _I, _P]),
+    "stts_duration_to_alignment": (_I, [_P, _P, _I, _I, _P]),
     "stts_length_regulate": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I, _P, _I, _I, _P, _I, _P]),
     "stts_upsample4": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "stts_to_time_major": (_I, [_P, _P, _I, _I, _I, _P, _I]),

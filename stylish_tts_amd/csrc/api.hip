@@ -63,12 +63,12 @@ int stts_finalize_weights(stts_ctx* c, int which) {
   API_BEGIN
   STTS_CHECK(c, "null ctx");
   STTS_HIP(hipSetDevice(c->device));
-  if (which & 1) STTS_TRY(finalize_frame(c));
-  if (which & 2) {
-    auto m = std::make_shared<PhonemeModel>();
-    STTS_TRY(finalize_phoneme(c, m.get()));
-    c->phoneme = m;
-    c->phoneme_ready = true;
+  if (which & (STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR)) STTS_TRY(finalize_frame(c, which));
+  const int ph = which & (STTS_W_SPEECH_TEXT | STTS_W_DURATION | STTS_W_PE_TEXT | STTS_W_PE_STYLE | STTS_W_PITCH_ENERGY);
+  if (ph) {
+    if (!c->phoneme) c->phoneme = std::make_shared<PhonemeModel>();
+    STTS_TRY(finalize_phoneme(c, static_cast<PhonemeModel*>(c->phoneme.get()), ph));
+    c->ready |= ph;
   }
   STTS_HIP(hipDeviceSynchronize());
   return 0;
@@ -91,8 +91,8 @@ int stts_check_status(stts_ctx* c, void* stream) {
 
 size_t stts_frame_workspace_bytes(const stts_ctx* c, int64_t rows, int n_utt, int max_len) { return frame_workspace_bytes(c, rows, n_utt, max_len); }
 
-#define SEG_CHECK()                                                                  \
-  STTS_CHECK(c && c->frame_ready, "frame-rate weights not finalized");               \
+#define SEG_CHECK(mask)                                                              \
+  STTS_CHECK(c && (c->ready & (mask)) == (mask), "weights for this stage are not finalized (need components 0x%x, have 0x%x)", (mask), c ? c->ready : 0); \
   STTS_CHECK(n_utt > 0 && seg_off_host && seg_off_dev && seg_off_host[0] == 0, "bad utterance offsets"); \
   for (int _u = 0; _u < n_utt; ++_u) STTS_CHECK(seg_off_host[_u + 1] > seg_off_host[_u], "utterance %d is empty", _u); \
   Seg s{n_utt, seg_off_host, seg_off_dev};                                           \
@@ -102,7 +102,7 @@ int stts_decoder_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* se
                          int ld_asr, const float* pitch, const float* energy, const float* style, float* x_out, int ld_x, void* ws,
                          size_t ws_bytes) {
   API_BEGIN
-  SEG_CHECK();
+  SEG_CHECK(STTS_W_DECODER);
   STTS_CHECK(ld_asr >= c->d.inter_dim && ld_asr % 4 == 0 && ld_x >= c->d.dec_hidden, "bad leading dimension");
   Arena a(ws, ws_bytes);
   return decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x_out, ld_x, a);
@@ -113,7 +113,7 @@ int stts_prior_flow_forward(stts_ctx* c, void* stream, int n_utt, const int32_t*
                             int ld_x, const float* style, const float* prior_noise, float* mel_out, int ld_mel, float* z_prior_out,
                             float* z_flow_out, void* ws, size_t ws_bytes) {
   API_BEGIN
-  SEG_CHECK();
+  SEG_CHECK(STTS_W_FLOW);
   STTS_CHECK(ld_x % 4 == 0 && ld_x >= c->d.dec_hidden && ld_mel >= c->d.dec_hidden, "bad leading dimension");
   Arena a(ws, ws_bytes);
   return prior_flow_forward(c, st, s, x, ld_x, style, prior_noise, mel_out, ld_mel, z_prior_out, z_flow_out, a);
@@ -124,7 +124,7 @@ int stts_harmonic_stft(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_
                        const float* src_noise, const float* init_phase, int batch_scope, float* prior_signal_out, float* har_spec,
                        float* har_phase, int ld_har, void* ws, size_t ws_bytes) {
   API_BEGIN
-  SEG_CHECK();
+  SEG_CHECK(STTS_W_GENERATOR);
   STTS_CHECK(ld_har >= kBins, "ld_har %d < %d", ld_har, kBins);
   Arena a(ws, ws_bytes);
   return harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, prior_signal_out, har_spec, har_phase, ld_har, a);
@@ -135,7 +135,7 @@ int stts_vocoder_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* se
                          int ld_mel, const float* style, const float* har_spec, const float* har_phase, int ld_har, float* audio_out,
                          float* logamp_out, float* phase_out, int ld_lp, void* ws, size_t ws_bytes) {
   API_BEGIN
-  SEG_CHECK();
+  SEG_CHECK(STTS_W_GENERATOR);
   STTS_CHECK(ld_mel % 4 == 0 && ld_har % 32 == 0 && ld_har >= round_up(kBins, 32), "har/mel leading dimension must cover 1056 columns, multiple of 32");
   STTS_CHECK(!logamp_out || ld_lp >= kBins, "ld_lp too small");
   Arena a(ws, ws_bytes);
@@ -147,7 +147,7 @@ int stts_frame_path(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off
                     const float* pitch, const float* energy, const float* style, const float* prior_noise, const float* src_noise,
                     const float* init_phase, int batch_scope, float* audio_out, void* ws, size_t ws_bytes) {
   API_BEGIN
-  SEG_CHECK();
+  SEG_CHECK(STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR);
   STTS_CHECK(ld_asr >= c->d.inter_dim && ld_asr % 4 == 0, "bad ld_asr");
   return frame_path(c, st, s, asr, ld_asr, pitch, energy, style, prior_noise, src_noise, init_phase, batch_scope, audio_out, ws, ws_bytes);
   API_END
@@ -198,8 +198,8 @@ int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, i
 }
 
 // ------------------------------------------------------------------------------------------------ phoneme-rate stages
-#define PH_CHECK()                                                                   \
-  STTS_CHECK(c && c->phoneme_ready, "phoneme-rate weights not finalized (stts_finalize_weights which & 2)"); \
+#define PH_CHECK(mask)                                                               \
+  STTS_CHECK(c && c->phoneme && (c->ready & (mask)) == (mask), "weights for this stage are not finalized (need components 0x%x, have 0x%x)", (mask), c ? c->ready : 0); \
   PhonemeModel& M = *static_cast<PhonemeModel*>(c->phoneme.get());                   \
   hipStream_t st = (hipStream_t)stream
 
@@ -216,7 +216,9 @@ size_t stts_phoneme_workspace_bytes(const stts_ctx* c, int64_t n_tokens, int64_t
 int stts_text_encoder_forward(stts_ctx* c, void* stream, int which, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
                               const int64_t* tokens, float* mu_out, int ld_mu, float* x_out, void* ws, size_t ws_bytes) {
   API_BEGIN
-  PH_CHECK();
+  const int te_mask[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_TEXT};
+  STTS_CHECK(which >= 0 && which < 3, "which must be 0 (duration), 1 (speech) or 2 (pitch/energy)");
+  PH_CHECK(te_mask[which]);
   STTS_CHECK(which >= 0 && which < 3, "which must be 0 (duration), 1 (speech) or 2 (pitch/energy)");
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   STTS_CHECK(ld_mu >= M.te[which].inter, "ld_mu too small");
@@ -229,7 +231,9 @@ int stts_text_encoder_forward(stts_ctx* c, void* stream, int which, int n_utt, c
 int stts_text_style_forward(stts_ctx* c, void* stream, int which, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev, const float* x,
                             int ldx, float* style_out, void* ws, size_t ws_bytes) {
   API_BEGIN
-  PH_CHECK();
+  const int se_mask[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_STYLE};
+  STTS_CHECK(which >= 0 && which < 3, "which must be 0, 1 or 2");
+  PH_CHECK(se_mask[which]);
   STTS_CHECK(which >= 0 && which < 3, "which must be 0, 1 or 2");
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   STTS_CHECK(ldx % 32 == 0 && ldx >= M.se[which].inter, "style encoder input: ld must be a multiple of 32 covering inter_dim");
@@ -242,7 +246,7 @@ int stts_text_style_forward(stts_ctx* c, void* stream, int which, int n_utt, con
 int stts_duration_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev, const int64_t* tokens,
                           float* logits_out, int32_t* dur_out, float* mu_out, float* style_out, float* prosody_out, void* ws, size_t ws_bytes) {
   API_BEGIN
-  PH_CHECK();
+  PH_CHECK(STTS_W_DURATION);
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   Seg s{n_utt, tok_off_host, tok_off_dev};
   Arena a(ws, ws_bytes);
@@ -255,13 +259,33 @@ int stts_pitch_energy_forward(stts_ctx* c, void* stream, int n_utt, const int32_
                               const float* pe_style, float* f0_out, float* energy_out, float* prosody_out, float* cross_out, void* ws,
                               size_t ws_bytes) {
   API_BEGIN
-  PH_CHECK();
+  PH_CHECK(STTS_W_PITCH_ENERGY);
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   STTS_TRY(seg_ok(n_utt, frm_off_host, frm_off_dev));
   STTS_CHECK(ld_enc >= c->d.pe_inter && ld_enc % 4 == 0, "bad ld_enc");
   Seg sp{n_utt, tok_off_host, tok_off_dev}, sf{n_utt, frm_off_host, frm_off_dev};
   Arena a(ws, ws_bytes);
   return pitch_energy_forward(c, M, st, sp, sf, dur, pe_enc, ld_enc, pe_style, f0_out, energy_out, prosody_out, cross_out, a);
+  API_END
+}
+
+int stts_duration_decode(void* stream, const float* logits, int ld, int n_rows, int32_t* dur_out) {
+  API_BEGIN
+  STTS_CHECK(logits && dur_out && ld >= 16 && n_rows > 0, "bad argument");
+  hipLaunchKernelGGL(duration_decode_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, (hipStream_t)stream, logits, ld, 16, n_rows, dur_out);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+int stts_duration_to_alignment(void* stream, const int32_t* dur, int n_tokens, int n_frames, float* alignment_out) {
+  API_BEGIN
+  STTS_CHECK(dur && alignment_out && n_tokens > 0 && n_tokens <= 1024 && n_frames > 0, "bad argument (at most 1024 tokens)");
+  const long total = (long)n_tokens * n_frames;
+  hipLaunchKernelGGL(alignment_matrix_kernel, dim3((unsigned)std::min<long>(1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dur, n_tokens,
+                     n_frames, alignment_out);
+  STTS_HIP(hipGetLastError());
+  return 0;
   API_END
 }
 

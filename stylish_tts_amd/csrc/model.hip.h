@@ -92,7 +92,7 @@ struct stts_ctx {
   std::map<std::string, stts::HostTensor> host;
   std::vector<void*> allocs;
   int* d_err = nullptr;
-  bool frame_ready = false;
+  int ready = 0;  // STTS_W_* components finalized
   // shared tables
   float* hann = nullptr;      // periodic Hann(win)
   float2* twiddle = nullptr;  // exp(-2 pi i m / n_fft), m < n_fft/2
@@ -118,7 +118,6 @@ struct stts_ctx {
   std::map<std::string, std::unique_ptr<stts::StyleTable>> op_tables;
   std::map<std::string, std::unique_ptr<stts::MrfW>> op_mrf;
   std::shared_ptr<void> phoneme;  // stts::PhonemeModel (phoneme_model.hip.h)
-  bool phoneme_ready = false;
 };
 
 namespace stts {
@@ -264,7 +263,7 @@ inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout
 // ------------------------------------------------------------------------------------------------
 // finalize: frame-rate path
 // ------------------------------------------------------------------------------------------------
-inline int finalize_frame(stts_ctx* c) {
+inline int finalize_frame(stts_ctx* c, int which) {
   const stts_model_dims& d = c->d;
   STTS_CHECK(d.n_fft == kNfft && d.win_length == kWin && d.hop_length / 4 == kHop && d.sample_rate == 24000,
              "this build is specialised for n_fft 2048 / win 1200 / hop 300 / 24 kHz (model.yml defaults)");
@@ -273,7 +272,7 @@ inline int finalize_frame(stts_ctx* c) {
              "this build is specialised for the default model.yml channel sizes");
   const std::string sp = "speech_predictor.";
   // tables
-  {
+  if (!c->hann) {
     std::vector<float> h(kWin);
     for (int i = 0; i < kWin; ++i) h[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / kWin));
     STTS_TRY(dev_upload(c, h, &c->hann));
@@ -285,7 +284,8 @@ inline int finalize_frame(stts_ctx* c) {
     STTS_TRY(dev_upload(c, tw64, &c->twiddle64));
   }
   // decoder (models/decoder.py:6-45)
-  {
+  if (which & STTS_W_DECODER) {
+    c->dec_style = StyleTable();
     HostTensor wf, wn;
     STTS_TRY(get_weight(c, sp + "decoder.F0_conv", &wf));
     STTS_TRY(get_weight(c, sp + "decoder.N_conv", &wn));
@@ -305,7 +305,8 @@ inline int finalize_frame(stts_ctx* c) {
     STTS_TRY(upload_table(c, &c->dec_style));
   }
   // prior + flow + post_flow (models/flow.py, models/speech_predictor.py:36-62)
-  {
+  if (which & STTS_W_FLOW) {
+    c->flow_style = StyleTable();
     const int fh = d.dec_hidden / 4, half = fh / 2;
     HostTensor wm, wl;
     STTS_TRY(get_weight(c, sp + "prior_encoder.proj_mean", &wm));
@@ -347,7 +348,8 @@ inline int finalize_frame(stts_ctx* c) {
     STTS_TRY(pack_plain(c, sp + "post_flow", true, 0, fh, &c->post_flow));
   }
   // generator (models/generator.py:340-438)
-  {
+  if (which & STTS_W_GENERATOR) {
+    c->gen_style = StyleTable();
     const std::string g = sp + "generator.";
     const int h = d.gen_hidden, hp = h / 2;
     STTS_TRY(pack_plain(c, g + "amp_prior_conv", true, 0, kBins, &c->amp_prior));
@@ -405,7 +407,7 @@ inline int finalize_frame(stts_ctx* c) {
     STTS_TRY(add_style(c, &c->gen_style, g + "phase_final_layer_norm", h, &c->head_phase));
     STTS_TRY(upload_table(c, &c->gen_style));
   }
-  c->frame_ready = true;
+  c->ready |= which & (STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR);
   return 0;
 }
 

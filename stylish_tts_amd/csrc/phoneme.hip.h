@@ -155,6 +155,24 @@ __global__ void __launch_bounds__(256) duration_decode_kernel(const float* __res
   dur[r] = (int)(hard < 7.0f ? hard : soft);
 }
 
+// DurationProcessor.duration_to_alignment (train/utils.py:476-489): 0/1 matrix [P, T], T = sum(dur); one thread per frame
+__global__ void __launch_bounds__(256) alignment_matrix_kernel(const int* __restrict__ dur, int P, int T, float* __restrict__ out) {
+  __shared__ int cum[1025];
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int i = 0; i < P; ++i) {
+      a += dur[i];
+      cum[i] = a;
+    }
+  }
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)P * T; i += (long)gridDim.x * 256) {
+    const int p = (int)(i / T), t = (int)(i % T);
+    const int lo = p == 0 ? 0 : cum[p - 1];
+    out[i] = (t >= lo && t < cum[p]) ? 1.0f : 0.0f;
+  }
+}
+
 // token-local index of the token each frame belongs to (build_monotonic_band_mask's tau = alignment.argmax(dim=1),
 // pitch_energy_predictor.py:201)
 __global__ void __launch_bounds__(256) local_token_kernel(const int* __restrict__ src_row, const int* __restrict__ frm_off,

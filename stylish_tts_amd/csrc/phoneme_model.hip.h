@@ -181,23 +181,27 @@ inline int pack_prosody(stts_ctx* c, const std::string& p, int d_model, int n_la
   return 0;
 }
 
-inline int finalize_phoneme(stts_ctx* c, PhonemeModel* M) {
+inline int finalize_phoneme(stts_ctx* c, PhonemeModel* M, int which) {
   const stts_model_dims& d = c->d;
   const int inter[3] = {d.inter_dim, d.inter_dim, d.pe_inter};
+  const int te_bit[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_TEXT};
+  const int se_bit[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_STYLE};
   for (int i = 0; i < 3; ++i) {
-    STTS_TRY(pack_text_encoder(c, kTextEncPrefix[i], inter[i], &M->te[i]));
-    STTS_TRY(pack_style_encoder(c, kStyleEncPrefix[i], inter[i], &M->se[i]));
+    if (which & te_bit[i]) STTS_TRY(pack_text_encoder(c, kTextEncPrefix[i], inter[i], &M->te[i]));
+    if (which & se_bit[i]) STTS_TRY(pack_style_encoder(c, kStyleEncPrefix[i], inter[i], &M->se[i]));
   }
-  {
+  if (which & STTS_W_DURATION) {
     DurationW& D = M->dur;
+    D = DurationW();
     STTS_TRY(pack_prosody(c, "duration_predictor.prosody_encoder.", d.inter_dim, d.dur_layers, &D.table, &D.pros));
     STTS_TRY(upload_table(c, &D.table));
     STTS_TRY(pack_plain(c, "duration_predictor.duration_proj.linear_layer", true, 0, D.pros.C, &D.proj));
     STTS_CHECK(d.dur_classes == 16, "duration decoding is specialised for the reference's 16-class table (train/utils.py:391-393)");
     D.ready = true;
   }
-  {
+  if (which & STTS_W_PITCH_ENERGY) {
     PitchEnergyW& P = M->pe;
+    P = PitchEnergyW();
     const std::string p = "pitch_energy_predictor.";
     STTS_TRY(pack_prosody(c, p + "prosody_encoder.", d.pe_inter, 3, &P.table, &P.pros));
     P.C = P.pros.C;

@@ -74,7 +74,7 @@ class HipModel:
             pass
 
     # ------------------------------------------------------------------ weights
-    def load_weights(self, weights: Mapping[str, Mapping[str, "np.ndarray | torch.Tensor"]], which: int = 1):
+    def load_weights(self, weights: Mapping[str, Mapping[str, "np.ndarray | torch.Tensor"]], which: int = 7):
         for mod, sd in weights.items():
             self.load_state_dict(mod, sd)
         self.finalize(which)
@@ -88,7 +88,7 @@ class HipModel:
             name = (module + "." if module else "") + prefix + k
             _lib.check(self.lib.stts_load_weight(self.ctx, name.encode(), a.ctypes.data_as(C.c_void_p), shape, max(a.ndim, 1)))
 
-    def finalize(self, which: int = 1):
+    def finalize(self, which: int = 7):
         _lib.check(self.lib.stts_finalize_weights(self.ctx, which))
 
     def check_status(self):

@@ -18,7 +18,7 @@ def hip(cfg, weights):
     from stylish_tts_amd.runtime import HipModel
 
     m = HipModel(cfg, 0)
-    m.load_weights({"speech_predictor": weights["speech_predictor"]}, which=1)
+    m.load_weights({"speech_predictor": weights["speech_predictor"]}, which=7)
     yield m
     m.close()
 

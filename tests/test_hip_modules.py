@@ -1,0 +1,157 @@
+"""GPU tests of the nn.Module shims (reference forward() signatures) and of the whole token -> waveform chain."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def mods(cfg):
+    from stylish_tts_amd import modules
+
+    return modules.build_inference_modules(cfg, synthetic_seed=0)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, rtol=2e-4, atol=None, what=""):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-6)
+    tol = atol if atol is not None else rtol * scale
+    err = np.abs(a - b).max()
+    assert err <= tol, f"{what}: max-abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
+
+
+def test_decoder_shim(mods, cfg):
+    from stylish_tts_amd import modules
+
+    g = load_golden("decoder")
+    d = modules.Decoder(dim_in=128, style_dim=64, dim_out=512, hidden_dim=512, residual_dim=64, cfg=cfg).load_synthetic(0)
+    x, f0 = d(dev(g["asr"]), dev(g["pitch"]), dev(g["energy"]), dev(g["style"]))
+    close(x, g["x"], what="Decoder.forward")
+    assert tuple(x.shape) == (1, 512, 64) and f0.shape == (1, 64)
+
+
+def test_duration_predictor_and_processor_shims(mods):
+    from stylish_tts_amd import modules
+
+    g = load_golden("duration_b2")
+    logits = mods["duration_predictor"](dev(g["texts"]), dev(g["lengths"]))
+    assert tuple(logits.shape) == (2, 12, 16)
+    close(logits[0], g["logits"][0], what="logits utt 0")
+    close(logits[1, 7:], g["logits"][1, 7:], what="padded positions return the bias like the reference")
+    g1 = load_golden("duration")
+    lg = mods["duration_predictor"](dev(g1["texts"]), dev(g1["lengths"]))
+    proc = modules.DurationProcessor(16, 50)
+    al = proc(lg[0], 12)
+    assert tuple(al.shape) == tuple(g1["alignment_shape"])
+    assert np.array_equal(al.sum(1).cpu().numpy(), g1["duration"])
+    assert bool((al.sum(0) == 1).all())  # every frame belongs to exactly one token (monotonic hard alignment)
+    gp = load_golden("duration_processor")
+    assert np.array_equal(proc.prediction_to_duration(dev(gp["logits"])).cpu().numpy(), gp["duration"].astype(np.int32))
+
+
+def test_text_and_style_encoder_shims(mods):
+    g = load_golden("pitch_energy")
+    mu, xh, mask = mods["pe_text_encoder"](dev(g["texts"]), dev(g["lengths"]))
+    close(mu, g["pe_text"], what="TextEncoder.forward mu")
+    assert tuple(mask.shape) == (1, 1, 12) and tuple(xh.shape) == (1, 128, 12)
+    sty = mods["pe_text_style_encoder"](mu, dev(g["lengths"]))
+    close(sty, g["pe_style"], what="TextStyleEncoder.forward")
+
+
+def test_pitch_energy_shim(mods):
+    from stylish_tts_amd import synth
+
+    g = load_golden("pitch_energy")
+    al = synth.alignment_from_durations(g["durations"])[None]
+    f0, n = mods["pitch_energy_predictor"](dev(g["pe_text"]), dev(g["lengths"]), dev(al), dev(g["pe_style"]))
+    close(f0, g["f0"], what="F0")
+    close(n, g["energy"], rtol=5e-4, what="N")
+
+
+def _staged_speech(eng, g, case, B):
+    """speech_predictor composition through the stage entry points with the reference's har_phase adopted at the
+    ill-conditioned bins (see oracle.align_branch) -> waveform comparable with the golden everywhere."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.runtime import Segments
+
+    d = np.atleast_2d(g["durations"]).astype(np.int32)
+    L = [int(x) for x in g["lengths"]]
+    T = [int(d[b, : L[b]].sum()) for b in range(B)]
+    sp, st = Segments(L, eng.device), Segments(T, eng.device)
+    st4 = st.scaled(4)
+    toks = dev(np.concatenate([g["texts"][b, : L[b]] for b in range(B)]))
+    dur = dev(np.concatenate([d[b, : L[b]] for b in range(B)]))
+    enc = eng.text_encoder(1, sp, toks)
+    style = eng.text_style(1, sp, enc)
+    asr = eng.length_regulate(sp, st4, dur, 4, enc, 128)
+    p4 = eng.upsample4(st, st4, dev(g["pitch"].reshape(-1)))
+    e4 = eng.upsample4(st, st4, dev(g["energy"].reshape(-1)))
+    nz = synth.path_noise(case, B, 4 * T[0])
+    pn = dev(nz["prior_noise"].transpose(0, 2, 1).reshape(-1, 128))
+    x = eng.decoder(st4, asr, p4, e4, style)
+    mel = eng.prior_flow(st4, x, style, pn)
+    spec, phase = eng.harmonic_stft(st4, p4, dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)))
+    T4 = 4 * T[0]
+    ph = phase.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
+    sp_ = spec.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
+    ph, bad = O.align_branch(ph, (g["cut_idx"].astype(np.int64), g["cut_phase"].astype(np.float32)), sp_, return_bad=True)
+    assert bad == 0
+    phz = np.zeros((B * T4, 1056), np.float32)
+    phz[:, :1025] = ph.transpose(0, 2, 1).reshape(B * T4, 1025)
+    audio = eng.vocoder(st4, mel, style, spec, dev(phz))
+    return audio.reshape(B, 1, -1), nz, (x, mel, spec, phase, style, st4)
+
+
+@pytest.mark.parametrize("name,case,B", [("speech_predictor", "sp1", 1), ("speech_predictor_b2", "sp2", 2)])
+def test_speech_predictor_golden_and_shim(mods, name, case, B):
+    from stylish_tts_amd import synth
+
+    g = load_golden(name)
+    spm = mods["speech_predictor"]
+    audio, nz, (x, mel, spec, phase, style, st4) = _staged_speech(spm.engine, g, case, B)
+    close(audio, g["audio"], atol=1e-3, what=f"{name} waveform (tokens -> audio)")
+    # the shim = the same stages without the test-side branch adoption
+    d = np.atleast_2d(g["durations"])
+    al = np.stack([synth.alignment_from_durations(v) for v in d])
+    pred = spm(dev(g["texts"]), dev(g["lengths"]), dev(al), dev(g["pitch"]), dev(g["energy"]), noise={k: dev(v) for k, v in nz.items()})
+    ref = spm.engine.vocoder(st4, mel, style, spec, phase).reshape(B, 1, -1)
+    assert torch.equal(pred.audio, ref)
+    assert tuple(pred.magnitude.shape) == (B, 1025, st4.lengths[0] + 1) and torch.equal(pred.magnitude[:, :, -1], pred.magnitude[:, :, -2])
+
+
+def test_export_model_end_to_end(mods):
+    """ExportModel.forward(texts, lengths, alignment) -> waveform.  Pitch is integrated over the utterance and har_phase
+    is discontinuous, so audio parity is checked with the reference's pitch/energy fed in (see tests/test_oracle_golden.py)."""
+    from stylish_tts_amd import modules, synth
+
+    g = load_golden("export_model")
+    em = modules.ExportModel(device="cuda", **mods)
+    proc = modules.DurationProcessor(16, 50)
+    texts, lengths = dev(g["texts"]), dev(g["lengths"])
+    logits = mods["duration_predictor"](texts, lengths)
+    al = proc(logits[0], 12).unsqueeze(0)
+    assert np.array_equal(al[0].sum(1).cpu().numpy(), g["duration"])
+    pe_enc, _, _ = mods["pe_text_encoder"](texts, lengths)
+    pe_sty = mods["pe_text_style_encoder"](pe_enc, lengths)
+    f0, n = mods["pitch_energy_predictor"](pe_enc, lengths, al, pe_sty)
+    close(f0, g["pitch"], atol=2e-2, what="predicted pitch [Hz]")
+    close(n, g["energy"], atol=2e-3, what="predicted energy")
+    T = al.shape[2]
+    nz = synth.path_noise("export", 1, 4 * T)
+    audio = em(texts, lengths, al, noise={k: dev(v) for k, v in nz.items()})
+    assert tuple(audio.shape) == (300 * T,) and bool(torch.isfinite(audio).all())
+    # teacher-forced: the reference's pitch/energy -> the reference's waveform
+    g2 = dict(g)
+    g2["durations"] = g["duration"].astype(np.int32)
+    a2, _, _ = _staged_speech(mods["speech_predictor"].engine, g2, "export", 1)
+    close(a2.reshape(-1), g["audio"], atol=1e-3, what="export waveform (teacher-forced pitch)")

@@ -14,7 +14,7 @@ def hip(cfg, weights):
     from stylish_tts_amd.runtime import HipModel
 
     m = HipModel(cfg, 0)
-    m.load_weights(weights, which=3)
+    m.load_weights(weights, which=255)
     yield m
     m.close()
 
