@@ -442,7 +442,7 @@ int stts_op_mrf_block(stts_ctx* c, void* stream, const char* prefix, int n_utt, 
 
 // ------------------------------------------------------------------------------------------------ kernel microbench
 // Times `iters` back-to-back launches of conv_gemm_f32 on synthetic data (tuning aid for tools/gemm_bench.py).
-extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int cin, int cout, int k, int tile, int iters, double* avg_ms) {
+extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int cin, int cout, int k, int tile, int iters, double* avg_ms, int tune) {
   API_BEGIN
   hipStream_t st = (hipStream_t)stream;
   const long R = (long)n_utt * rows_per_utt;
@@ -471,7 +471,7 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   Seg s{n_utt, h.data(), so};
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, X, kc, 0, pc);
-  a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy;
+  a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy; a.tune = tune;
   hipEvent_t e0, e1;
   STTS_HIP(hipEventCreate(&e0));
   STTS_HIP(hipEventCreate(&e1));

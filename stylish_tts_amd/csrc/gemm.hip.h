@@ -51,6 +51,7 @@ struct GemmArgs {
   int nseg;
   const int* seg_off;  // device [n_utt + 1], rows
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
+  int tune;               // experiment switches (bit 0: priority stagger between co-resident blocks)
   int N;               // output channels actually stored (paired epilogues: channels of the result)
   const float* bias;   // [Npad] in packed row order, may be null
   // EPI_STORE
@@ -113,44 +114,51 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 xr[XL], wr[WL];
-  // iteration cursor of the NEXT tile to load.  The current segment lives in scalar registers: indexing
-  // a.seg[] with a run-time value would make the compiler copy the kernarg struct to scratch / LDS.
+  // ---- K-loop cursor.  The loop body is ONE basic block (no data-dependent branches): loads are unconditional from a
+  // clamped row and zeroed by select, the cursor advances with scalar selects, and the current segment's fields sit in
+  // scalar registers.  That lets the scheduler sink the address arithmetic, the global loads and the ds_writes into the
+  // shadows of the MFMAs (one 32x32x2 MFMA occupies the matrix pipe for 64 cycles but issues in ~8).
   int s = 0, tap = 0, chunk = 0;
-  GemmSeg g = a.seg[0];
-  auto next_seg = [&]() {
-    if (s == 1) g = a.seg[1];
-    else if (s == 2) g = a.seg[2];
-  };
+  const float* gX = a.seg[0].X + a.seg[0].xcol0;
+  const float* gW = a.seg[0].W + (long)utt * a.seg[0].w_utt_stride + (long)m0 * a.seg[0].ntaps * a.seg[0].kc;
+  int g_ldx = a.seg[0].ldx, g_kc = a.seg[0].kc, g_ntaps = a.seg[0].ntaps, g_dil = a.seg[0].dil, g_pad = a.seg[0].pad;
+  const int nseg = a.nseg;
 
+  f32x4 xr[XL], wr[WL];
   auto gload = [&]() {
-    const int shift = (tap - g.pad) * g.dil;
-    const float* xb = g.X + g.xcol0 + chunk * 32;
+    const int shift = (tap - g_pad) * g_dil;
+    const int wrow = g_ntaps * g_kc;
+    const float* xb = gX + chunk * 32;
+    const float* wb = gW + tap * g_kc + chunk * 32;
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
       const int grow = row0 + r + shift;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (grow >= lo && grow < hi) v = *reinterpret_cast<const f32x4*>(xb + (long)grow * g.ldx + sl * 4);
-      xr[i] = v;
+      const bool ok = grow >= lo && grow < hi;
+      const int crow = min(max(grow, lo), hi - 1);
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)crow * g_ldx + sl * 4);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      xr[i] = ok ? v : z;
     }
-    const float* wb = g.W + (long)utt * g.w_utt_stride + ((long)m0 * g.ntaps + tap) * g.kc + chunk * 32;
-    const long wrow = (long)g.ntaps * g.kc;
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int idx = tid + i * NT;
       const int n = idx >> 3, sl = idx & 7;
       wr[i] = *reinterpret_cast<const f32x4*>(wb + n * wrow + sl * 4);
     }
-    // advance cursor
-    if (++chunk * 32 >= g.kc) {
-      chunk = 0;
-      if (++tap >= g.ntaps) {
-        tap = 0;
-        ++s;
-        next_seg();
-      }
+    // advance (scalar selects; the last tile is simply re-loaded when the cursor would run off the end)
+    const bool wrapc = (chunk + 1) * 32 >= g_kc;
+    const bool wrapt = wrapc && (tap + 1 >= g_ntaps);
+    const bool last = wrapt && (s + 1 >= nseg);
+    chunk = last ? chunk : (wrapc ? 0 : chunk + 1);
+    tap = last ? tap : (wrapt ? 0 : (wrapc ? tap + 1 : tap));
+    if (wrapt && !last) {  // uniform, taken at most twice per kernel
+      ++s;
+      const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
+      gX = n.X + n.xcol0;
+      gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+      g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
     }
   };
   auto lstore = [&](int b) {
@@ -174,41 +182,46 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
   if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / 32);
   if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / 32);
 
-  gload();
+  gload();     // tile 0
   lstore(0);
+  gload();     // tile 1 (or tile 0 again when total == 1) stays in registers
   __syncthreads();
 
   const int l31 = lane & 31, lh = lane >> 5;
-  for (int it = 0; it < total; ++it) {
-    const bool more = it + 1 < total;
-    if (more) gload();
-    const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
-    const f32x4* Ws = Xs + BN * 8;
+  auto mma_step = [&](const f32x4* Xs, const f32x4* Ws, int kk) {
+    const int slot = 2 * kk + lh;
+    f32x4 xa[TR], wb[TC];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int slot = 2 * kk + lh;
-      f32x4 xa[TR], wb[TC];
+    for (int i = 0; i < TR; ++i) {
+      const int r = wn * WR + i * 32 + l31;
+      xa[i] = Xs[r * 8 + (slot ^ ((r >> 1) & 7))];
+    }
 #pragma unroll
-      for (int i = 0; i < TR; ++i) {
-        const int r = wn * WR + i * 32 + l31;
-        xa[i] = Xs[r * 8 + (slot ^ ((r >> 1) & 7))];
-      }
+    for (int j = 0; j < TC; ++j) {
+      const int c = wm * WC + j * 32 + l31;
+      wb[j] = Ws[c * 8 + (slot ^ ((c >> 1) & 7))];
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
-        const int c = wm * WC + j * 32 + l31;
-        wb[j] = Ws[c * 8 + (slot ^ ((c >> 1) & 7))];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].x, wb[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].y, wb[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, wb[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < TR; ++i)
-#pragma unroll
-        for (int j = 0; j < TC; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].x, wb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].y, wb[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, wb[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (more) lstore((it + 1) & 1);
+  };
+  // iteration `it` computes tile it from buffer it&1 while tile it+1 moves registers -> the other buffer (legal: that
+  // buffer was last read in iteration it-1 and a barrier has passed) and tile it+2 is fetched into the freed registers.
+  for (int it = 0; it < total; ++it) {
+    const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
+    const f32x4* Ws = Xs + BN * 8;
+    mma_step(Xs, Ws, 0);
+    lstore((it + 1) & 1);
+    mma_step(Xs, Ws, 1);
+    gload();
+    mma_step(Xs, Ws, 2);
+    mma_step(Xs, Ws, 3);
     __syncthreads();
   }
 

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stylish_tts_amd import _lib
 lib = C.CDLL(_lib.LIB_PATH)
-lib.stts_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+lib.stts_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
 torch.zeros(1).cuda()
 shapes = [  # name, cin, cout, k
     ("out_conv 768->1025 k7", 768, 1025, 7), ("out_conv 768->1024 k7", 768, 1024, 7),
@@ -14,12 +14,16 @@ shapes = [  # name, cin, cout, k
     ("square 4096 (1 utt)", 4096, 4096, 1),
 ]
 B, T4 = int(os.environ.get("B", 8)), 960
+flt = os.environ.get("SHAPES")
+tiles = [int(t) for t in os.environ.get("TILES", "1,2,3").split(",")]
 for name, cin, cout, k in shapes:
+    if flt and not any(f in name for f in flt.split(",")):
+        continue
     line = f"{name:26s}"
-    for tile in (1, 2, 3):
+    for tile in tiles:
         ms = C.c_double()
         nu, rows = (1, 4096) if name.startswith("square") else (B, T4)
-        rc = lib.stts_bench_gemm(None, nu, rows, cin, cout, k, tile, 10, C.byref(ms))
+        rc = lib.stts_bench_gemm(None, nu, rows, cin, cout, k, tile, 10, C.byref(ms), int(os.environ.get('TUNE', 0)))
         assert rc == 0
         fl = 2.0 * nu * rows * cout * cin * k
         line += f"  tile{tile}: {ms.value*1e3:8.1f} us {fl/ms.value/1e9:6.1f} TF"
