@@ -1,0 +1,218 @@
+// wn_layer_kernel: one WaveNet layer of the reverse flow in ONE launch (models/flow.py:70-87):
+//   x_in = wn-conv1d k5 (h)                      128 -> 256
+//   acts = tanh(x_in[:128] + g[:128]) * sigmoid(x_in[128:] + g[128:])        (fused_add_tanh_sigmoid_multiply, flow.py:7-14)
+//   rs   = wn-Linear(acts)                       128 -> 256 (last layer: 128)
+//   h   += rs[:128] ; out += rs[128:]            (last layer: out += rs)
+// As two conv_gemm_f32 launches (gate epilogue, then split-accumulate epilogue) a B = 8 batch gives one wave per SIMD
+// and two launches per layer for 3 GFLOP.  Here a block owns 32 time rows x all 256 gate columns, so the gated
+// activations never leave the CU: phase 1 contracts K = 5 taps x 128 channels from HBM/L2 tiles, the gate epilogue
+// writes acts [32 x 128] into LDS, phase 2 contracts K = 128 with the A operand read straight from LDS, and the
+// epilogue updates h / out.  8 waves per block = 4 column groups x 2 K-groups (the K-groups split every 32-channel
+// chunk in halves and are summed through LDS), i.e. two waves per SIMD that cover each other's staging.
+// h is double buffered (Hin -> Hout): neighbouring blocks still read this block's Hin rows as their conv halo.
+#pragma once
+#include "gemm.hip.h"
+
+namespace stts {
+
+struct WnArgs {
+  const float* Hin;    // [rows, 128]
+  float* Hout;         // [rows, 128] (may be null on the last layer)
+  float* Out;          // [rows, 128]
+  const int* seg_off;
+  const float* Win;    // packed paired [256][5][128]
+  const float* bin;    // [256] packed order
+  const float* Wrs;    // packed plain [n_rs padded to 128][1][128]
+  const float* brs;    // [n_rs]
+  const float* gate;   // [n_utt][ld_gate]
+  int ld_gate, gcol0;
+  int n_rs;            // 256 (layers 0..n-2: h-part | out-part) or 128 (last layer: out only)
+  int out_acc;         // accumulate into Out (0 on the first layer: output = zeros + ...)
+};
+
+__global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
+  constexpr int RT = 32, C = 128, NG = 256, TAPS = 5, PAD = 2;
+  constexpr int STG = (RT + NG) * 8;  // f32x4 per staging buffer
+  __shared__ f32x4 stage[2 * STG];    // 73,728 B
+  __shared__ f32x4 acts[RT * 32];     // 16 KB: [32-channel chunk][row][8 slots], same swizzle as the staging tiles
+
+  const int utt = blockIdx.y;
+  const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
+  const int row0 = lo + blockIdx.x * RT;
+  if (row0 >= hi) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int kg = wid >> 2, wc = wid & 3;  // K-group, column group (64 packed columns)
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+  // ------------------------------------------------------------------ phase 1: gate GEMM, K = 5 taps x 4 chunks of 32
+  f32x4 xr, wr[4];
+  int it_load = 0;  // next (tap, chunk) to fetch
+  auto gload1 = [&]() {
+    const int t = min(it_load, TAPS * 4 - 1);
+    const int tap = t >> 2, chunk = t & 3;
+    if (tid < 256) {
+      const int r = tid >> 3, sl = tid & 7;
+      const int grow = row0 + r + tap - PAD;
+      const bool ok = grow >= lo && grow < hi;
+      const int crow = min(max(grow, lo), hi - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.Hin + (long)crow * C + chunk * 32 + sl * 4);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      xr = ok ? v : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 512;
+      const int n = idx >> 3, sl = idx & 7;
+      wr[i] = *reinterpret_cast<const f32x4*>(a.Win + ((long)n * TAPS + tap) * C + chunk * 32 + sl * 4);
+    }
+    ++it_load;
+  };
+  auto lstore = [&](int b, bool with_x) {
+    f32x4* Xs = stage + b * STG;
+    f32x4* Ws = Xs + RT * 8;
+    if (with_x && tid < 256) {
+      const int r = tid >> 3, sl = tid & 7;
+      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xr;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 512;
+      const int n = idx >> 3, sl = idx & 7;
+      Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = wr[i];
+    }
+  };
+  // one kk step: A fragment (32 rows) from `As` (f32x4 index of row r, slot s), two B fragments from Ws
+  auto mma = [&](const f32x4 xa, const f32x4* Ws, int kk) {
+    const int slot = 2 * kk + lh;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cidx = wc * 64 + j * 32 + l31;
+      const f32x4 wb = Ws[cidx * 8 + (slot ^ ((cidx >> 1) & 7))];
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, wb.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, wb.y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, wb.z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, wb.w, acc[j], 0, 0, 0);
+    }
+  };
+
+  gload1();
+  lstore(0, true);
+  gload1();
+  __syncthreads();
+  for (int it = 0; it < TAPS * 4; ++it) {
+    const f32x4* Xs = stage + (it & 1) * STG;
+    const f32x4* Ws = Xs + RT * 8;
+    {
+      const int kk = 2 * kg, slot = 2 * kk + lh;
+      mma(Xs[l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+    }
+    lstore((it + 1) & 1, true);
+    {
+      const int kk = 2 * kg + 1, slot = 2 * kk + lh;
+      mma(Xs[l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+    }
+    gload1();
+    __syncthreads();
+  }
+
+  // K-group reduction through LDS (staging is free now), then the gate epilogue into `acts`
+  float* red = reinterpret_cast<float*>(stage);  // [wc][j][r][lane] : 4 * 2 * 16 * 64 floats = 32 KB
+  if (kg == 1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wc * 2 + j) * 16 + r) * 64 + lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (kg == 0) {
+    const int ch = wc * 32 + l31;  // activation channel of this lane
+    const float ba = a.bin[wc * 64 + l31], bb = a.bin[wc * 64 + 32 + l31];
+    const float ga = a.gate[(long)utt * a.ld_gate + a.gcol0 + ch], gb = a.gate[(long)utt * a.ld_gate + a.gcol0 + C + ch];
+    float* af = reinterpret_cast<float*>(acts);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float va = acc[0][r] + red[((wc * 2 + 0) * 16 + r) * 64 + lane] + ba + ga;
+      const float vb = acc[1][r] + red[((wc * 2 + 1) * 16 + r) * 64 + lane] + bb + gb;
+      const float act = tanhf(va) * (1.0f / (1.0f + __expf(-vb)));
+      const int chunk = ch >> 5, slot = (ch >> 2) & 7;
+      af[(chunk * (RT * 8) + row * 8 + (slot ^ ((row >> 1) & 7))) * 4 + (ch & 3)] = act;
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ phase 2: res/skip GEMM, K = 128 from LDS acts
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+  const bool col_active = wc * 64 < a.n_rs;  // last layer: only 128 output columns
+  int c_load = 0;
+  auto gload2 = [&]() {
+    const int chunk = min(c_load, 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 512;
+      const int n = idx >> 3, sl = idx & 7;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      wr[i] = n < a.n_rs ? *reinterpret_cast<const f32x4*>(a.Wrs + (long)n * C + chunk * 32 + sl * 4) : z;
+    }
+    ++c_load;
+  };
+  gload2();
+  lstore(0, false);
+  gload2();
+  __syncthreads();
+  for (int it = 0; it < 4; ++it) {
+    const f32x4* Ws = stage + (it & 1) * STG + RT * 8;
+    if (col_active) {
+      const int kk = 2 * kg, slot = 2 * kk + lh;
+      mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+    }
+    lstore((it + 1) & 1, false);
+    if (col_active) {
+      const int kk = 2 * kg + 1, slot = 2 * kk + lh;
+      mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+    }
+    gload2();
+    __syncthreads();
+  }
+  if (kg == 1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wc * 2 + j) * 16 + r) * 64 + lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (kg == 0 && col_active) {
+    const int nvalid = hi - row0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = wc * 64 + j * 32 + l31;
+      const float bv = a.brs[n];
+      const bool to_h = a.n_rs == 2 * C && n < C;  // first half of a 256-wide res/skip goes to h, the rest to out
+      const int col = (a.n_rs == 2 * C && n >= C) ? n - C : n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < nvalid) {
+          const long g = (long)(row0 + row) * C + col;
+          const float v = acc[j][r] + red[((wc * 2 + j) * 16 + r) * 64 + lane] + bv;
+          if (to_h) {
+            a.Hout[g] = a.Hin[g] + v;
+          } else {
+            a.Out[g] = a.out_acc ? a.Out[g] + v : v;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace stts
