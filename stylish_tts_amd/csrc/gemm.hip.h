@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
   const int nseg = a.nseg;
 
   f32x4 xr[XL], wr[WL];
+  bool xok[XL];  // rows outside the utterance: zeroed when the registers are consumed (lstore), so the load stays in flight
   auto gload = [&]() {
     const int shift = (tap - g_pad) * g_dil;
     const int wrow = g_ntaps * g_kc;
@@ -137,9 +138,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
       const int grow = row0 + r + shift;
       const bool ok = grow >= lo && grow < hi;
       const int crow = min(max(grow, lo), hi - 1);
-      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)crow * g_ldx + sl * 4);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xr[i] = ok ? v : z;
+      xr[i] = *reinterpret_cast<const f32x4*>(xb + (long)crow * g_ldx + sl * 4);
+      xok[i] = ok;
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
-      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xr[i];
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xok[i] ? xr[i] : z;
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {

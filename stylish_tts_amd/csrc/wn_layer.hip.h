@@ -11,6 +11,8 @@
 // chunk in halves and are summed through LDS), i.e. two waves per SIMD that cover each other's staging.
 // h is double buffered (Hin -> Hout): neighbouring blocks still read this block's Hin rows as their conv halo.
 #pragma once
+#include <type_traits>
+
 #include "gemm.hip.h"
 
 namespace stts {
@@ -51,43 +53,49 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
   // ------------------------------------------------------------------ phase 1: gate GEMM, K = 5 taps x 4 chunks of 32
-  f32x4 xr, wr[4];
-  int it_load = 0;  // next (tap, chunk) to fetch
-  auto gload1 = [&]() {
-    const int t = min(it_load, TAPS * 4 - 1);
+  // Staging pipeline: an iteration is only 16 MFMAs per wave (~1 us per SIMD), shorter than a loaded-memory round trip,
+  // so tiles are fetched TWO iterations ahead into two register sets (set = tile parity) and moved to LDS one iteration
+  // ahead: iteration `it` computes tile it from buffer it&1, stores tile it+1 (fetched during it-2) and fetches tile it+3.
+  // two explicit register sets (named, not an array indexed by the set: that would be demoted to LDS/scratch)
+  struct RegSet {
+    f32x4 x, w[4];
+    bool ok;
+  };
+  RegSet rs0, rs1;
+  rs0.ok = rs1.ok = false;
+  auto gload1 = [&](RegSet& rs, int t) {
+    t = min(t, TAPS * 4 - 1);
     const int tap = t >> 2, chunk = t & 3;
     if (tid < 256) {
       const int r = tid >> 3, sl = tid & 7;
       const int grow = row0 + r + tap - PAD;
       const bool ok = grow >= lo && grow < hi;
       const int crow = min(max(grow, lo), hi - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.Hin + (long)crow * C + chunk * 32 + sl * 4);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xr = ok ? v : z;
+      rs.x = *reinterpret_cast<const f32x4*>(a.Hin + (long)crow * C + chunk * 32 + sl * 4);
+      rs.ok = ok;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 512;
       const int n = idx >> 3, sl = idx & 7;
-      wr[i] = *reinterpret_cast<const f32x4*>(a.Win + ((long)n * TAPS + tap) * C + chunk * 32 + sl * 4);
+      rs.w[i] = *reinterpret_cast<const f32x4*>(a.Win + ((long)n * TAPS + tap) * C + chunk * 32 + sl * 4);
     }
-    ++it_load;
   };
-  auto lstore = [&](int b, bool with_x) {
+  auto lstore = [&](const RegSet& rs, int b, bool with_x) {
     f32x4* Xs = stage + b * STG;
     f32x4* Ws = Xs + RT * 8;
     if (with_x && tid < 256) {
       const int r = tid >> 3, sl = tid & 7;
-      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xr;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = rs.ok ? rs.x : z;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 512;
       const int n = idx >> 3, sl = idx & 7;
-      Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = wr[i];
+      Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = rs.w[i];
     }
   };
-  // one kk step: A fragment (32 rows) from `As` (f32x4 index of row r, slot s), two B fragments from Ws
   auto mma = [&](const f32x4 xa, const f32x4* Ws, int kk) {
     const int slot = 2 * kk + lh;
 #pragma unroll
@@ -100,50 +108,73 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, wb.w, acc[j], 0, 0, 0);
     }
   };
+  // exchange between the two K-groups: each group keeps the half of the 16 accumulator rows it will finish
+  // (kg 0: r < 8, kg 1: r >= 8) and hands the other half over through LDS.
+  float* red = reinterpret_cast<float*>(stage);  // [wc][j][r][lane] : 4 * 2 * 16 * 64 floats = 32 KB
+  // Accumulator registers must only ever be indexed by compile-time constants (a run-time index demotes the vector
+  // to memory, and the compiler even re-merges two static branches into one dynamic loop).  So K-group 1 first swaps
+  // its register halves with conditional moves; afterwards BOTH groups finish registers 0..7 and hand over 8..15,
+  // and only the logical row number (an ordinary integer) depends on the group: ro = r + 8*kg resp. r - 8*kg.
+  auto exchange = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float lo8 = acc[j][r], hi8 = acc[j][r + 8];
+        acc[j][r] = kg ? hi8 : lo8;
+        acc[j][r + 8] = kg ? lo8 : hi8;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 8; r < 16; ++r) red[((wc * 2 + j) * 16 + (r - 8 * kg)) * 64 + lane] = acc[j][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[j][r] += red[((wc * 2 + j) * 16 + (r + 8 * kg)) * 64 + lane];
+  };
 
-  gload1();
-  lstore(0, true);
-  gload1();
+  gload1(rs0, 0);
+  lstore(rs0, 0, true);
+  gload1(rs1, 1);
+  gload1(rs0, 2);
   __syncthreads();
-  for (int it = 0; it < TAPS * 4; ++it) {
+  auto iter1 = [&](int it, RegSet& nset) {  // nset: register set holding tile it+1
     const f32x4* Xs = stage + (it & 1) * STG;
     const f32x4* Ws = Xs + RT * 8;
     {
       const int kk = 2 * kg, slot = 2 * kk + lh;
       mma(Xs[l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
-    lstore((it + 1) & 1, true);
+    lstore(nset, (it + 1) & 1, true);
+    gload1(nset, it + 3);
     {
       const int kk = 2 * kg + 1, slot = 2 * kk + lh;
       mma(Xs[l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
-    gload1();
     __syncthreads();
+  };
+  for (int it = 0; it < TAPS * 4; it += 2) {
+    iter1(it, rs1);
+    iter1(it + 1, rs0);
   }
 
-  // K-group reduction through LDS (staging is free now), then the gate epilogue into `acts`
-  float* red = reinterpret_cast<float*>(stage);  // [wc][j][r][lane] : 4 * 2 * 16 * 64 floats = 32 KB
-  if (kg == 1) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wc * 2 + j) * 16 + r) * 64 + lane] = acc[j][r];
-  }
-  __syncthreads();
-  if (kg == 0) {
+  exchange();
+  {
     const int ch = wc * 32 + l31;  // activation channel of this lane
     const float ba = a.bin[wc * 64 + l31], bb = a.bin[wc * 64 + 32 + l31];
     const float ga = a.gate[(long)utt * a.ld_gate + a.gcol0 + ch], gb = a.gate[(long)utt * a.ld_gate + a.gcol0 + C + ch];
     float* af = reinterpret_cast<float*>(acts);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    const int chunk = ch >> 5, slot = (ch >> 2) & 7;
+    auto gate_one = [&](float xa, float xb, int r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float va = acc[0][r] + red[((wc * 2 + 0) * 16 + r) * 64 + lane] + ba + ga;
-      const float vb = acc[1][r] + red[((wc * 2 + 1) * 16 + r) * 64 + lane] + bb + gb;
-      const float act = tanhf(va) * (1.0f / (1.0f + __expf(-vb)));
-      const int chunk = ch >> 5, slot = (ch >> 2) & 7;
-      af[(chunk * (RT * 8) + row * 8 + (slot ^ ((row >> 1) & 7))) * 4 + (ch & 3)] = act;
-    }
+      const float va = xa + ba + ga, vb = xb + bb + gb;
+      const float th = 1.0f - 2.0f / (__expf(2.0f * va) + 1.0f);  // tanh
+      af[(chunk * (RT * 8) + row * 8 + (slot ^ ((row >> 1) & 7))) * 4 + (ch & 3)] = th * (1.0f / (1.0f + __expf(-vb)));
+    };
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gate_one(acc[0][r], acc[1][r], r + 8 * kg);
   }
   __syncthreads();
 
@@ -153,44 +184,41 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
   const bool col_active = wc * 64 < a.n_rs;  // last layer: only 128 output columns
-  int c_load = 0;
-  auto gload2 = [&]() {
-    const int chunk = min(c_load, 3);
+  auto gload2 = [&](RegSet& rs, int chunk) {
+    chunk = min(chunk, 3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 512;
       const int n = idx >> 3, sl = idx & 7;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      wr[i] = n < a.n_rs ? *reinterpret_cast<const f32x4*>(a.Wrs + (long)n * C + chunk * 32 + sl * 4) : z;
+      rs.w[i] = n < a.n_rs ? *reinterpret_cast<const f32x4*>(a.Wrs + (long)n * C + chunk * 32 + sl * 4) : z;
     }
-    ++c_load;
   };
-  gload2();
-  lstore(0, false);
-  gload2();
+  gload2(rs0, 0);
+  lstore(rs0, 0, false);
+  gload2(rs1, 1);
+  gload2(rs0, 2);
   __syncthreads();
-  for (int it = 0; it < 4; ++it) {
+  auto iter2 = [&](int it, RegSet& nset) {
     const f32x4* Ws = stage + (it & 1) * STG + RT * 8;
     if (col_active) {
       const int kk = 2 * kg, slot = 2 * kk + lh;
       mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
-    lstore((it + 1) & 1, false);
+    lstore(nset, (it + 1) & 1, false);
+    gload2(nset, it + 3);
     if (col_active) {
       const int kk = 2 * kg + 1, slot = 2 * kk + lh;
       mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
-    gload2();
     __syncthreads();
+  };
+  for (int it = 0; it < 4; it += 2) {
+    iter2(it, rs1);
+    iter2(it + 1, rs0);
   }
-  if (kg == 1) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wc * 2 + j) * 16 + r) * 64 + lane] = acc[j][r];
-  }
-  __syncthreads();
-  if (kg == 0 && col_active) {
+  exchange();
+  if (col_active) {
     const int nvalid = hi - row0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -198,19 +226,20 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
       const float bv = a.brs[n];
       const bool to_h = a.n_rs == 2 * C && n < C;  // first half of a 256-wide res/skip goes to h, the rest to out
       const int col = (a.n_rs == 2 * C && n >= C) ? n - C : n;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      auto put = [&](float x, int r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < nvalid) {
           const long g = (long)(row0 + row) * C + col;
-          const float v = acc[j][r] + red[((wc * 2 + j) * 16 + r) * 64 + lane] + bv;
+          const float v = x + bv;
           if (to_h) {
             a.Hout[g] = a.Hin[g] + v;
           } else {
             a.Out[g] = a.out_acc ? a.Out[g] + v : v;
           }
         }
-      }
+      };
+#pragma unroll
+      for (int r = 0; r < 8; ++r) put(acc[j][r], r + 8 * kg);
     }
   }
 }
