@@ -97,14 +97,13 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
   const int lo = seg_off[u], hi = seg_off[u + 1];
   const int r0 = lo + blockIdx.y * 64;
   if (r0 >= hi) return;
-  const int c4 = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
-  if (c4 >= ldy) return;
-  float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f};
+  // the block's 64 channels: one thread per channel merges the chunk statistics, result shared through LDS
+  __shared__ float s_sc[64], s_sh[64], s_al[64];
   const float n = (float)(hi - lo);
   const int nch = (hi - lo + kStatChunk - 1) / kStatChunk;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = c4 + k;
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float scv = 0.f, shv = 0.f, alv = 1.f;
     if (c < C) {
       float mean = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
@@ -121,10 +120,24 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
       }
       const float rstd = rsqrtf(m2 / n + eps);
       const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
-      sc[k] = rstd * (1.0f + g);
-      sh[k] = be - mean * sc[k];
-      if (alpha) al[k] = alpha[c];
+      scv = rstd * (1.0f + g);
+      shv = be - mean * scv;
+      if (alpha) alv = alpha[c];
     }
+    s_sc[threadIdx.x] = scv;
+    s_sh[threadIdx.x] = shv;
+    s_al[threadIdx.x] = alv;
+  }
+  __syncthreads();
+  const int cl = (threadIdx.x & 15) * 4;
+  const int c4 = blockIdx.x * 64 + cl;
+  if (c4 >= ldy) return;
+  float sc[4], sh[4], al[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sc[k] = s_sc[cl + k];
+    sh[k] = s_sh[cl + k];
+    al[k] = s_al[cl + k];
   }
   const int rend = min(hi, r0 + 64);
   for (int r = r0 + (threadIdx.x >> 4); r < rend; r += 16) {

@@ -124,9 +124,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
   int g_ldx = a.seg[0].ldx, g_kc = a.seg[0].kc, g_ntaps = a.seg[0].ntaps, g_dil = a.seg[0].dil, g_pad = a.seg[0].pad;
   const int nseg = a.nseg;
 
-  f32x4 xr[XL], wr[WL];
-  bool xok[XL];  // rows outside the utterance: zeroed when the registers are consumed (lstore), so the load stays in flight
-  auto gload = [&]() {
+  // Two named register sets: tiles are fetched TWO iterations ahead (an iteration is ~2 us of matrix-pipe time per
+  // SIMD, about one loaded-memory round trip) and moved to LDS one iteration ahead.
+  struct RegSet {
+    f32x4 x[XL], w[WL];
+    bool ok[XL];  // rows outside the utterance are zeroed when the registers are consumed (lstore), so the load stays in flight
+  };
+  RegSet rsA, rsB;
+  auto gload = [&](RegSet& rs) {
     const int shift = (tap - g_pad) * g_dil;
     const int wrow = g_ntaps * g_kc;
     const float* xb = gX + chunk * 32;
@@ -136,16 +141,15 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
       const int grow = row0 + r + shift;
-      const bool ok = grow >= lo && grow < hi;
       const int crow = min(max(grow, lo), hi - 1);
-      xr[i] = *reinterpret_cast<const f32x4*>(xb + (long)crow * g_ldx + sl * 4);
-      xok[i] = ok;
+      rs.x[i] = *reinterpret_cast<const f32x4*>(xb + (long)crow * g_ldx + sl * 4);
+      rs.ok[i] = grow >= lo && grow < hi;
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int idx = tid + i * NT;
       const int n = idx >> 3, sl = idx & 7;
-      wr[i] = *reinterpret_cast<const f32x4*>(wb + n * wrow + sl * 4);
+      rs.w[i] = *reinterpret_cast<const f32x4*>(wb + n * wrow + sl * 4);
     }
     // advance (scalar selects; the last tile is simply re-loaded when the cursor would run off the end)
     const bool wrapc = (chunk + 1) * 32 >= g_kc;
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
       g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
     }
   };
-  auto lstore = [&](int b) {
+  auto lstore = [&](const RegSet& rs, int b) {
     f32x4* Xs = lds + b * (BN + BM) * 8;
     f32x4* Ws = Xs + BN * 8;
 #pragma unroll
@@ -169,13 +173,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xok[i] ? xr[i] : z;
+      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = rs.ok[i] ? rs.x[i] : z;
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int idx = tid + i * NT;
       const int n = idx >> 3, sl = idx & 7;
-      Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = wr[i];
+      Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = rs.w[i];
     }
   };
 
@@ -183,9 +187,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
   if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / 32);
   if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / 32);
 
-  gload();     // tile 0
-  lstore(0);
-  gload();     // tile 1 (or tile 0 again when total == 1) stays in registers
+  gload(rsA);  // tile 0
+  lstore(rsA, 0);
+  gload(rsB);  // tile 1
+  gload(rsA);  // tile 2   (the cursor clamps at the last tile, extra fetches are harmless re-loads)
   __syncthreads();
 
   const int l31 = lane & 31, lh = lane >> 5;
@@ -212,18 +217,23 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);
       }
   };
-  // iteration `it` computes tile it from buffer it&1 while tile it+1 moves registers -> the other buffer (legal: that
-  // buffer was last read in iteration it-1 and a barrier has passed) and tile it+2 is fetched into the freed registers.
-  for (int it = 0; it < total; ++it) {
+  // iteration `it` computes tile it from buffer it&1; tile it+1 (fetched during iteration it-2) moves registers -> the
+  // other buffer (legal: that buffer was last read in iteration it-1 and a barrier has passed); then tile it+3 is fetched
+  // into the freed register set.
+  auto iter = [&](int it, RegSet& nset) {
     const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
     const f32x4* Ws = Xs + BN * 8;
     mma_step(Xs, Ws, 0);
-    lstore((it + 1) & 1);
+    lstore(nset, (it + 1) & 1);
     mma_step(Xs, Ws, 1);
-    gload();
+    gload(nset);
     mma_step(Xs, Ws, 2);
     mma_step(Xs, Ws, 3);
     __syncthreads();
+  };
+  for (int it = 0; it < total; it += 2) {
+    iter(it, rsB);
+    if (it + 1 < total) iter(it + 1, rsA);
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -383,14 +393,19 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     STTS_CHECK(a.seg[i].kc % 32 == 0 && a.seg[i].ldx % 4 == 0 && a.seg[i].xcol0 % 4 == 0, "conv_gemm: segment %d misaligned (kc %d ldx %d xcol0 %d)", i,
                a.seg[i].kc, a.seg[i].ldx, a.seg[i].xcol0);
   }
+  // Tile choice from tools/gemm_bench.py on MI355X (B = 8 x 960 rows): 128x128 with 8 waves once that fills the chip
+  // (>= 200 blocks), 128(cout) x 64(rows) with 4 waves for the mid-size layers, 128 x 32 for the small ones.
   const long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
   int tile = force_tile;
-  if (tile == 0) tile = blocks128 >= 400 ? 1 : (blocks128 >= 100 ? 2 : 3);
+  if (tile == 0) tile = blocks128 >= 200 ? 5 : (blocks128 >= 100 ? 2 : 3);
+  if (tile == 5 && epi != EPI_STORE && epi != EPI_SPLIT_ACC) tile = 2;  // paired epilogues need 64-column wave tiles
   GemmProfiler& prof = gemm_profiler();
   if (prof.on) (void)hipEventRecord(prof.next(), st);
   switch (tile) {
     case 1: launch_cfg<128, 128, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
     case 2: launch_cfg<128, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
+    case 4: launch_cfg<64, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;      // experiment: 4-5 blocks/CU
+    case 5: launch_cfg<128, 128, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;    // experiment: 8 waves per block
     default: launch_cfg<128, 32, 2, 1>(st, a, epi, npad, n_utt, max_rows); break;
   }
   if (prof.on) {
