@@ -87,9 +87,13 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
-__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const GemmArgs a) {
-  constexpr int NT = WARPS_M * WARPS_N * 64;
+// KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
+// partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
+// have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
+  constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
+  static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
   constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
   constexpr int TR = WR / 32, TC = WC / 32;
   constexpr int XL = BN * 8 / NT, WL = BM * 8 / NT;
@@ -103,8 +107,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
   const int row0 = lo + blockIdx.y * BN;
   if (row0 >= hi) return;
   const int m0 = blockIdx.x * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kg = (tid >> 6) / (WARPS_M * WARPS_N), wid = (tid >> 6) % (WARPS_M * WARPS_N);  // K-group, wave position
   const int wn = wid / WARPS_M, wm = wid % WARPS_M;
+  (void)kg;
 
   f32x16 acc[TR][TC];
 #pragma unroll
@@ -223,12 +229,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
   auto iter = [&](int it, RegSet& nset) {
     const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
     const f32x4* Ws = Xs + BN * 8;
-    mma_step(Xs, Ws, 0);
-    lstore(nset, (it + 1) & 1);
-    mma_step(Xs, Ws, 1);
-    gload(nset);
-    mma_step(Xs, Ws, 2);
-    mma_step(Xs, Ws, 3);
+    if constexpr (KSPLIT == 1) {
+      mma_step(Xs, Ws, 0);
+      lstore(nset, (it + 1) & 1);
+      mma_step(Xs, Ws, 1);
+      gload(nset);
+      mma_step(Xs, Ws, 2);
+      mma_step(Xs, Ws, 3);
+    } else {
+      mma_step(Xs, Ws, 2 * kg);
+      lstore(nset, (it + 1) & 1);
+      gload(nset);
+      mma_step(Xs, Ws, 2 * kg + 1);
+    }
     __syncthreads();
   };
   for (int it = 0; it < total; it += 2) {
@@ -236,6 +249,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_gemm_f32(const Gem
     if (it + 1 < total) iter(it + 1, rsA);
   }
 
+  if constexpr (KSPLIT == 2) {
+    // sum the two K-groups: group 1 parks its accumulators in LDS (the staging buffers are free now), group 0 adds them
+    // and runs the epilogue alone.
+    static_assert(WARPS_M * WARPS_N * TR * TC * 16 * 64 * 4 <= 2 * (BN + BM) * 8 * 16, "reduction buffer must fit in the staging LDS");
+    float* red = reinterpret_cast<float*>(lds);
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((wid * TR + i) * TC + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((wid * TR + i) * TC + j) * 16 + r) * 64 + lane];
+  }
   // ------------------------------------------------------------------ epilogue
   // acc[i][j][r]: row = wn*WR + i*32 + (r&3) + 8*(r>>2) + 4*lh ; col = wm*WC + j*32 + l31
   const int nvalid = hi - row0;  // rows of this tile inside the utterance
@@ -369,17 +404,17 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
   return 2.0 * (double)a.rows_total * (double)a.wrows * k;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KS = 1>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows) {
-  dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt), block(WM * WN * 64);
+  dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt), block(WM * WN * 64 * KS);
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE>), grid, block, 0, st, a); break;
-    case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC>), grid, block, 0, st, a); break;
+    case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS>), grid, block, 0, st, a); break;
+    case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS>), grid, block, 0, st, a); break;
     default:
       if constexpr (BM / WM >= 64) {
-        if (epi == EPI_GATE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE>), grid, block, 0, st, a);
-        else if (epi == EPI_COUPLE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR>), grid, block, 0, st, a);
+        if (epi == EPI_GATE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS>), grid, block, 0, st, a);
+        else if (epi == EPI_COUPLE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS>), grid, block, 0, st, a);
       }
       break;
   }
@@ -397,15 +432,21 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // (>= 200 blocks), 128(cout) x 64(rows) with 4 waves for the mid-size layers, 128 x 32 for the small ones.
   const long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
   int tile = force_tile;
-  if (tile == 0) tile = blocks128 >= 200 ? 5 : (blocks128 >= 100 ? 2 : 3);
-  if (tile == 5 && epi != EPI_STORE && epi != EPI_SPLIT_ACC) tile = 2;  // paired epilogues need 64-column wave tiles
+  const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
+  if (tile == 0) tile = blocks128 >= 200 ? (paired ? 2 : 5) : (blocks128 >= 24 ? (paired ? 2 : 6) : 3);
+  // (intra-block K-split, tiles 8-10, and 2-wave tiles measured no better than these at any layer shape: every
+  //  configuration plateaus at ~80 % matrix-pipe occupancy)
   GemmProfiler& prof = gemm_profiler();
   if (prof.on) (void)hipEventRecord(prof.next(), st);
   switch (tile) {
     case 1: launch_cfg<128, 128, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
     case 2: launch_cfg<128, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
     case 4: launch_cfg<64, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;      // experiment: 4-5 blocks/CU
-    case 5: launch_cfg<128, 128, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;    // experiment: 8 waves per block
+    case 5: launch_cfg<128, 128, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;    // 8 waves per block
+    case 6: launch_cfg<128, 64, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
+    case 8: launch_cfg<128, 128, 4, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 16 waves: 8 positions x 2 K-groups
+    case 9: launch_cfg<128, 128, 2, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 8 waves: 4 positions (64x64) x 2 K-groups
+    case 10: launch_cfg<128, 64, 2, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 8 waves: 4 positions (32x64) x 2 K-groups
     default: launch_cfg<128, 32, 2, 1>(st, a, epi, npad, n_utt, max_rows); break;
   }
   if (prof.on) {
