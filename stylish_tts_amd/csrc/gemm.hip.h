@@ -102,11 +102,24 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
   __shared__ f32x4 lds[2 * (BN + BM) * 8];
 
-  const int utt = blockIdx.z;
+  // XCD-aware block -> tile map (guide T1; speed only, any placement is correct): workgroups are dealt round-robin
+  // over the 8 XCDs, each with its own L2.  Re-number them so that one XCD works through a CONTIGUOUS range of
+  // tiles with the cout tile as the fastest index: all cout tiles of a row tile then share their X rows in one L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = bx + gx * (by + gy * bz);
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    bx = id % gx;
+    by = (id / gx) % gy;
+    bz = id / (gx * gy);
+  }
+  const int utt = bz;
   const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
-  const int row0 = lo + blockIdx.y * BN;
+  const int row0 = lo + by * BN;
   if (row0 >= hi) return;
-  const int m0 = blockIdx.x * BM;
+  const int m0 = bx * BM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int kg = (tid >> 6) / (WARPS_M * WARPS_N), wid = (tid >> 6) % (WARPS_M * WARPS_N);  // K-group, wave position
   const int wn = wid / WARPS_M, wm = wid % WARPS_M;
@@ -157,12 +170,15 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       const int n = idx >> 3, sl = idx & 7;
       rs.w[i] = *reinterpret_cast<const f32x4*>(wb + n * wrow + sl * 4);
     }
-    // advance (scalar selects; the last tile is simply re-loaded when the cursor would run off the end)
-    const bool wrapc = (chunk + 1) * 32 >= g_kc;
-    const bool wrapt = wrapc && (tap + 1 >= g_ntaps);
+    // advance: TAP is the inner index, so the taps of one 32-channel chunk re-read (almost) the same rows of X
+    // back to back and hit L1/L2; channel-inner order re-streamed the whole X tile per tap from the fabric (rocprof
+    // FETCH_SIZE was ~10x the compulsory bytes).  Scalar selects only; the last tile is re-loaded when the cursor
+    // would run off the end.
+    const bool wrapt1 = tap + 1 >= g_ntaps;
+    const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);  // segment finished
     const bool last = wrapt && (s + 1 >= nseg);
-    chunk = last ? chunk : (wrapc ? 0 : chunk + 1);
-    tap = last ? tap : (wrapt ? 0 : (wrapc ? tap + 1 : tap));
+    tap = last ? tap : (wrapt1 ? 0 : tap + 1);
+    chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
     if (wrapt && !last) {  // uniform, taken at most twice per kernel
       ++s;
       const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
@@ -298,7 +314,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         if (a.sumsq_part) {
           ss += __shfl_xor(ss, 32, 64);
           if (lh == 0 && nok) {
-            const long t = (long)utt * a.ss_stride + blockIdx.y * (BN / 32) + (wn * TR + i);
+            const long t = (long)utt * a.ss_stride + by * (BN / 32) + (wn * TR + i);
             a.sumsq_part[t * a.ld_ss + n] = ss;
           }
         }
