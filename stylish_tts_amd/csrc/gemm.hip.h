@@ -150,26 +150,36 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     bool ok[XL];  // rows outside the utterance are zeroed when the registers are consumed (lstore), so the load stays in flight
   };
   RegSet rsA, rsB;
+  // Addressing: uniform (scalar) base pointers + 32-bit per-thread byte offsets, so the loads use the saddr form and the
+  // per-iteration vector arithmetic is a clamp, a multiply and an add per X row (the W offsets are loop invariant).
+  // Offsets are relative to the utterance / the weight tile, hence always < 2^31 bytes.
+  unsigned woff[WL];
+  const int len = hi - lo, rel0 = row0 - lo;
+  auto seg_offsets = [&]() {
+    const int wrow = g_ntaps * g_kc;
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + i * NT;
+      woff[i] = (unsigned)(((idx >> 3) * wrow + (idx & 7) * 4) * 4);
+    }
+  };
+  seg_offsets();
   auto gload = [&](RegSet& rs) {
     const int shift = (tap - g_pad) * g_dil;
-    const int wrow = g_ntaps * g_kc;
-    const float* xb = gX + chunk * 32;
-    const float* wb = gW + tap * g_kc + chunk * 32;
+    const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + chunk * 32);
+    const char* wb = reinterpret_cast<const char*>(gW + tap * g_kc + chunk * 32);
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
-      const int grow = row0 + r + shift;
-      const int crow = min(max(grow, lo), hi - 1);
-      rs.x[i] = *reinterpret_cast<const f32x4*>(xb + (long)crow * g_ldx + sl * 4);
-      rs.ok[i] = grow >= lo && grow < hi;
+      const int rel = rel0 + r + shift;
+      const int crel = min(max(rel, 0), len - 1);
+      const unsigned off = (unsigned)((crel * g_ldx + sl * 4) * 4);
+      rs.x[i] = *reinterpret_cast<const f32x4*>(xb + off);
+      rs.ok[i] = rel >= 0 && rel < len;
     }
 #pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const int idx = tid + i * NT;
-      const int n = idx >> 3, sl = idx & 7;
-      rs.w[i] = *reinterpret_cast<const f32x4*>(wb + n * wrow + sl * 4);
-    }
+    for (int i = 0; i < WL; ++i) rs.w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
     // advance: TAP is the inner index, so the taps of one 32-channel chunk re-read (almost) the same rows of X
     // back to back and hit L1/L2; channel-inner order re-streamed the whole X tile per tap from the fabric (rocprof
     // FETCH_SIZE was ~10x the compulsory bytes).  Scalar selects only; the last tile is re-loaded when the cursor
@@ -185,6 +195,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       gX = n.X + n.xcol0;
       gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
       g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+      seg_offsets();
     }
   };
   auto lstore = [&](const RegSet& rs, int b) {
@@ -242,23 +253,26 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // iteration `it` computes tile it from buffer it&1; tile it+1 (fetched during iteration it-2) moves registers -> the
   // other buffer (legal: that buffer was last read in iteration it-1 and a barrier has passed); then tile it+3 is fetched
   // into the freed register set.
+  int return_guard = 0;
+  (void)return_guard;
   auto iter = [&](int it, RegSet& nset) {
     const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
     const f32x4* Ws = Xs + BN * 8;
     if constexpr (KSPLIT == 1) {
       mma_step(Xs, Ws, 0);
-      lstore(nset, (it + 1) & 1);
+      if (!(a.tune & 4)) lstore(nset, (it + 1) & 1);
       mma_step(Xs, Ws, 1);
-      gload(nset);
+      if (!(a.tune & 8)) gload(nset);
       mma_step(Xs, Ws, 2);
       mma_step(Xs, Ws, 3);
+      if (a.tune & 2) return_guard = 1;  // ablation only (tools/gemm_bench.py): skip the barrier -> results are wrong
     } else {
       mma_step(Xs, Ws, 2 * kg);
       lstore(nset, (it + 1) & 1);
       gload(nset);
       mma_step(Xs, Ws, 2 * kg + 1);
     }
-    __syncthreads();
+    if (!(a.tune & 2)) __syncthreads();
   };
   for (int it = 0; it < total; it += 2) {
     iter(it, rsB);
