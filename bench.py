@@ -58,8 +58,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step (BASELINE cfg2 = 8; other values are side experiments)")
+    ap.add_argument("--mel-frames", type=int, default=240, help="mel frames per utterance (cfg2 = 240 = 3.0 s)")
     ap.add_argument("--cpu-utts", type=int, default=4, help="utterances the CPU baseline times (bounded sample)")
     args = ap.parse_args()
+    global BATCH, T_MEL, T4
+    BATCH, T_MEL = args.batch, args.mel_frames
+    T4 = 4 * T_MEL
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +149,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "cfg2: LJSpeech-shaped batch=8 x 3.0 s (T=240 mel frames, 72000 samples @24 kHz) fp32, "
+            "workload": ("cfg2: " if (BATCH, T_MEL) == (8, 240) else "side experiment: ") + f"LJSpeech-shaped batch={BATCH} x {T_MEL / 80:.1f} s (T={T_MEL} mel frames, {T4 * 75} samples @24 kHz) fp32, "
                         "Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); no diffusion step exists in the reference",
             "batch_per_gpu": BATCH,
             "global_batch": BATCH * world,

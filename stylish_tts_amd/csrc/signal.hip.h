@@ -217,27 +217,43 @@ __global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ sig
 // generator.py:425-426).  X = exp(logamp) * (cos(phase) + i sin(phase)) (generator.py:428-430), Hermitian
 // extension (imag of DC / Nyquist ignored like a C2R transform), inverse FFT, 1/N, window.
 // yw rows: utterance u starts at seg_off[u] + u.
+// The Hermitian spectrum makes the output real, so the 2048-point inverse runs as ONE 1024-point complex transform:
+//   E[k] = (X[k] + conj(X[H-k]))/2 ,  O[k] = (X[k] - conj(X[H-k]))/2 * e^{+2 pi i k/N} ,  Z[k] = E[k] + i O[k]  (H = N/2)
+//   z = IFFT_H(Z) / H ;  x[2n] = Re z[n], x[2n+1] = Im z[n]
 __global__ void __launch_bounds__(256) istft_frames_kernel(const float* __restrict__ logamp, const float* __restrict__ phase, int ld,
                                                            const int* __restrict__ seg_off, const float* __restrict__ hann,
                                                            const float2* __restrict__ twiddle, float* __restrict__ yw) {
-  __shared__ float2 A[kNfft], Bf[kNfft], tw[kNfft / 2];
+  constexpr int H = kNfft / 2;
+  __shared__ float2 Xs[H + 1], A[H], Bf[H], tw[H];
   const int u = blockIdx.y, f = blockIdx.x;
   const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
   if (f > nfr) return;
   const long row = lo + min(f, nfr - 1);
-  for (int i = threadIdx.x; i < kNfft / 2; i += 256) tw[i] = twiddle[i];
+  for (int i = threadIdx.x; i < H; i += 256) tw[i] = twiddle[i];  // exp(-2 pi i m / N), m < H
   for (int k = threadIdx.x; k < kBins; k += 256) {
     const float a = expf(logamp[row * ld + k]);
     const float p = phase[row * ld + k];
     float re = a * cosf(p), im = a * sinf(p);
-    if (k == 0 || k == kNfft / 2) im = 0.f;
-    A[k] = make_float2(re, im);
-    if (k > 0 && k < kNfft / 2) A[kNfft - k] = make_float2(re, -im);
+    if (k == 0 || k == H) im = 0.f;  // a C2R transform ignores them (torch.istft / pocketfft)
+    Xs[k] = make_float2(re, im);
   }
   __syncthreads();
-  const float2* y = fft_lds<float2, kNfft, true>(A, Bf, tw, 1);
+  for (int k = threadIdx.x; k < H; k += 256) {
+    const float2 x = Xs[k], y = Xs[H - k];
+    const float er = 0.5f * (x.x + y.x), ei = 0.5f * (x.y - y.y);   // E = (X[k] + conj(X[H-k]))/2
+    const float dr = 0.5f * (x.x - y.x), di = 0.5f * (x.y + y.y);   // D = (X[k] - conj(X[H-k]))/2
+    const float2 w = tw[k];                                          // conj(w) = e^{+2 pi i k/N}
+    const float orr = dr * w.x + di * w.y, oi = di * w.x - dr * w.y; // O = D * conj(w)
+    A[k] = make_float2(er - oi, ei + orr);                           // Z = E + i O
+  }
+  __syncthreads();
+  const float2* z = fft_lds<float2, H, true>(A, Bf, tw, 2);
   float* o = yw + (long)(lo + u + f) * kWin;
-  for (int i = threadIdx.x; i < kWin; i += 256) o[i] = y[kWinLo + i].x * (1.0f / kNfft) * hann[i];
+  for (int i = threadIdx.x; i < kWin; i += 256) {
+    const int n = kWinLo + i;
+    const float2 v = z[n >> 1];
+    o[i] = ((n & 1) ? v.y : v.x) * (1.0f / H) * hann[i];
+  }
 }
 
 // Overlap-add + window-envelope normalisation + centre trim + tanh (generator.py:432-433; torch.istft).
