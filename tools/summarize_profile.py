@@ -1,0 +1,32 @@
+"""Summarise a `rocprofv3 --kernel-trace --stats` run of bench.py into profiles/ (per-kernel ms/step, and the
+contraction kernels' average launch duration to set beside bench.py's HIP-event figure)."""
+import csv, glob, json, sys
+
+src, out_prefix, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+f = glob.glob(src + "/*/*kernel_stats.csv")[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+lines = ["| kernel | launches/step | ms/step | avg us | share |", "|---|---|---|---|---|"]
+g_ns = g_calls = 0
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+    n = r["Name"].replace("stts::", "").replace("void ", "").split("(")[0]
+    t, c = float(r["TotalDurationNs"]), int(r["Calls"])
+    if "conv_gemm_f32" in n or "wn_layer" in n:
+        g_ns += t
+        g_calls += c
+    if t / tot > 0.002:
+        lines.append(f"| `{n}` | {c / steps:.1f} | {t / 1e6 / steps:.3f} | {t / c / 1e3:.1f} | {100 * t / tot:.1f} % |")
+summary = {
+    "source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (20 timed + 3 warm-up + 3 profiled steps)",
+    "steps_in_trace": steps,
+    "gpu_busy_ms_per_step": tot / 1e6 / steps,
+    "contraction_kernels": "conv_gemm_f32<*> + wn_layer_kernel",
+    "contraction_launches_per_step": g_calls / steps,
+    "contraction_avg_launch_us": g_ns / g_calls / 1e3,
+    "contraction_ms_per_step": g_ns / 1e6 / steps,
+    "algorithmic_gflop_per_step": 568.36,
+    "contraction_tflops_from_rocprof": 568.36e9 / (g_ns / steps * 1e-9) / 1e12,
+}
+open(out_prefix + "_summary.json", "w").write(json.dumps(summary, indent=1))
+open(out_prefix + "_kernels.md", "w").write("\n".join(lines) + "\n")
+print(json.dumps(summary, indent=1))
