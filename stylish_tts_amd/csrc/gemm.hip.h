@@ -51,7 +51,8 @@ struct GemmArgs {
   int nseg;
   const int* seg_off;  // device [n_utt + 1], rows
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
-  int tune;               // experiment switches (bit 0: priority stagger between co-resident blocks)
+  int tune;               // experiment switches (tools/gemm_bench.py ablations)
+  const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
   int N;               // output channels actually stored (paired epilogues: channels of the result)
   const float* bias;   // [Npad] in packed row order, may be null
   // EPI_STORE
@@ -90,7 +91,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
 // partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
 // have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
   static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
@@ -166,13 +167,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   seg_offsets();
   auto gload = [&](RegSet& rs) {
     const int shift = (tap - g_pad) * g_dil;
-    const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + chunk * 32);
-    const char* wb = reinterpret_cast<const char*>(gW + tap * g_kc + chunk * 32);
+    const bool hot = a.tune & 16;  // ablation only: every tile read hits the same few KB (L1/L2 resident) -> wrong results
+    const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + (hot ? 0 : chunk * 32));
+    const char* wb = reinterpret_cast<const char*>((hot ? a.seg[0].W : gW) + (hot ? 0 : tap * g_kc + chunk * 32));
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
-      const int rel = rel0 + r + shift;
+      const int rel = (hot ? 0 : rel0) + r + shift;
       const int crel = min(max(rel, 0), len - 1);
       const unsigned off = (unsigned)((crel * g_ldx + sl * 4) * 4);
       rs.x[i] = *reinterpret_cast<const f32x4*>(xb + off);
@@ -220,12 +222,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / 32);
   if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / 32);
 
-  gload(rsA);  // tile 0
-  lstore(rsA, 0);
-  gload(rsB);  // tile 1
-  gload(rsA);  // tile 2   (the cursor clamps at the last tile, extra fetches are harmless re-loads)
-  __syncthreads();
-
   const int l31 = lane & 31, lh = lane >> 5;
   auto mma_step = [&](const f32x4* Xs, const f32x4* Ws, int kk) {
     const int slot = 2 * kk + lh;
@@ -250,6 +246,74 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);
       }
   };
+
+  if constexpr (GLDS) {
+    // ---- LDS-DMA staging: global_load_lds writes 64 lanes x 16 B = 8 tile rows straight into LDS (no VGPR round trip,
+    // no ds_write, no mid-loop waits).  The destination is lane-linear, so the 16-byte-slot swizzle is applied to the
+    // SOURCE slot each lane fetches (guide 5.4 rule 21); rows outside the utterance fetch from a page of zeros.
+    static_assert(KSPLIT == 1, "GLDS path is single K-group");
+    constexpr int NW = NT / 64, NI = (BN + BM) / 8;  // wave-instructions per tile
+    static_assert(NI % NW == 0, "tile rows must divide over the waves");
+    const int wv = tid >> 6;
+    auto issue = [&](int b) {
+      const int shift = (tap - g_pad) * g_dil;
+      const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + chunk * 32);
+      const char* wb = reinterpret_cast<const char*>(gW + tap * g_kc + chunk * 32);
+      const int wrow = g_ntaps * g_kc;
+#pragma unroll
+      for (int q = 0; q < NI / NW; ++q) {
+        const int inst = wv + q * NW;             // 8-row group of the combined [X rows | W rows] tile
+        const int trow = inst * 8 + (lane >> 3);  // row in the combined tile
+        const char* src;
+        if (inst < BN / 8) {                      // wave-uniform
+          const int r = trow;
+          const int sslot = (lane & 7) ^ ((r >> 1) & 7);
+          const int rel = rel0 + r + shift;
+          const bool ok = rel >= 0 && rel < len;
+          src = ok ? xb + (unsigned)((rel * g_ldx + sslot * 4) * 4) : reinterpret_cast<const char*>(a.zeros);
+        } else {
+          const int n = trow - BN;
+          const int sslot = (lane & 7) ^ ((n >> 1) & 7);
+          src = wb + (unsigned)((n * wrow + sslot * 4) * 4);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + b * (BN + BM) * 8 + inst * 64), 16, 0, 0);
+      }
+      // advance the cursor (same order as the register path)
+      const bool wrapt1 = tap + 1 >= g_ntaps;
+      const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
+      const bool last = wrapt && (s + 1 >= nseg);
+      tap = last ? tap : (wrapt1 ? 0 : tap + 1);
+      chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
+      if (wrapt && !last) {
+        ++s;
+        const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
+        gX = n.X + n.xcol0;
+        gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+        g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+      }
+    };
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+      issue((it + 1) & 1);  // tile it+1 (the cursor re-issues the last tile at the end: harmless, nobody reads it)
+      const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
+      const f32x4* Ws = Xs + BN * 8;
+      mma_step(Xs, Ws, 0);
+      mma_step(Xs, Ws, 1);
+      mma_step(Xs, Ws, 2);
+      mma_step(Xs, Ws, 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+  gload(rsA);  // tile 0
+  lstore(rsA, 0);
+  gload(rsB);  // tile 1
+  gload(rsA);  // tile 2   (the cursor clamps at the last tile, extra fetches are harmless re-loads)
+  __syncthreads();
+
   // iteration `it` computes tile it from buffer it&1; tile it+1 (fetched during iteration it-2) moves registers -> the
   // other buffer (legal: that buffer was last read in iteration it-1 and a barrier has passed); then tile it+3 is fetched
   // into the freed register set.
@@ -265,7 +329,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       if (!(a.tune & 8)) gload(nset);
       mma_step(Xs, Ws, 2);
       mma_step(Xs, Ws, 3);
-      if (a.tune & 2) return_guard = 1;  // ablation only (tools/gemm_bench.py): skip the barrier -> results are wrong
     } else {
       mma_step(Xs, Ws, 2 * kg);
       lstore(nset, (it + 1) & 1);
@@ -277,6 +340,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   for (int it = 0; it < total; it += 2) {
     iter(it, rsB);
     if (it + 1 < total) iter(it + 1, rsA);
+  }
   }
 
   if constexpr (KSPLIT == 2) {
@@ -428,23 +492,31 @@ inline GemmProfiler& gemm_profiler() {
   static GemmProfiler p;
   return p;
 }
+inline const float* zero_page() {
+  static float* z = nullptr;
+  if (!z) {
+    (void)hipMalloc(&z, 256);
+    (void)hipMemset(z, 0, 256);
+  }
+  return z;
+}
 inline double gemm_algorithmic_flops(const GemmArgs& a) {
   double k = 0;
   for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].kreal * a.seg[i].ntaps;
   return 2.0 * (double)a.rows_total * (double)a.wrows * k;
 }
 
-template <int BM, int BN, int WM, int WN, int KS = 1>
+template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt), block(WM * WN * 64 * KS);
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS>), grid, block, 0, st, a); break;
-    case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS>), grid, block, 0, st, a); break;
+    case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL>), grid, block, 0, st, a); break;
+    case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL>), grid, block, 0, st, a); break;
     default:
       if constexpr (BM / WM >= 64) {
-        if (epi == EPI_GATE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS>), grid, block, 0, st, a);
-        else if (epi == EPI_COUPLE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS>), grid, block, 0, st, a);
+        if (epi == EPI_GATE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS, GL>), grid, block, 0, st, a);
+        else if (epi == EPI_COUPLE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS, GL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, GL>), grid, block, 0, st, a);
       }
       break;
   }
@@ -469,14 +541,12 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   GemmProfiler& prof = gemm_profiler();
   if (prof.on) (void)hipEventRecord(prof.next(), st);
   switch (tile) {
-    case 1: launch_cfg<128, 128, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
     case 2: launch_cfg<128, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
-    case 4: launch_cfg<64, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;      // experiment: 4-5 blocks/CU
     case 5: launch_cfg<128, 128, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;    // 8 waves per block
     case 6: launch_cfg<128, 64, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
+    case 11: launch_cfg<128, 128, 4, 2, 1, true>(st, a, epi, npad, n_utt, max_rows); break;  // LDS-DMA staging, 8 waves
+    case 13: launch_cfg<128, 64, 4, 2, 1, true>(st, a, epi, npad, n_utt, max_rows); break;   // LDS-DMA staging, 64-row tile
     case 8: launch_cfg<128, 128, 4, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 16 waves: 8 positions x 2 K-groups
-    case 9: launch_cfg<128, 128, 2, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 8 waves: 4 positions (64x64) x 2 K-groups
-    case 10: launch_cfg<128, 64, 2, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 8 waves: 4 positions (32x64) x 2 K-groups
     default: launch_cfg<128, 32, 2, 1>(st, a, epi, npad, n_utt, max_rows); break;
   }
   if (prof.on) {

@@ -453,6 +453,7 @@ inline GemmArgs gemm_args(const Seg& s) {
   a.seg_off = s.dev;
   a.rows_total = s.rows();
   a.alpha = 1.0f;
+  a.zeros = zero_page();
   return a;
 }
 inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, const PackedConv& w, int pad = -1, int dil = 1) {

@@ -1,0 +1,59 @@
+"""tokens → waveforms: the whole inference chain on packed, ragged batches.
+
+The reference has no packaged inferencer (README roadmap): its callers loop per utterance over
+DurationPredictor → DurationProcessor → ExportModel (``train/test_onnx.py:48-79``, ``train/stage_type.py:483-523``).
+This is that composition for a list of utterances of any lengths in ONE pass: every stage runs on the packed
+sequences (per-utterance semantics, no padding), with a single host read in the middle for the predicted frame counts
+(the same round trip the reference has at ``test_onnx.py:65-66``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .runtime import HipModel, Segments
+
+
+class Synthesizer:
+    """engine: a HipModel with all components finalized (load_weights(..., which=255))."""
+
+    def __init__(self, engine: HipModel):
+        self.eng = engine
+        self.cfg = engine.cfg
+
+    @torch.no_grad()
+    def __call__(self, token_lists: Sequence[Sequence[int]], noise: Optional[Dict[str, torch.Tensor]] = None, return_details: bool = False):
+        eng, dev = self.eng, self.eng.device
+        L = [len(t) for t in token_lists]
+        toks = torch.tensor([int(v) for t in token_lists for v in t], dtype=torch.int64, device=dev)
+        sp = Segments(L, dev)
+        # 1. durations (DurationPredictor + DurationProcessor.prediction_to_duration)
+        _, dur = eng.duration(sp, toks)
+        csum = torch.cumsum(dur, 0)
+        ends = csum[torch.as_tensor(sp.host[1:].astype(np.int64) - 1, device=dev)]
+        T = torch.diff(ends, prepend=torch.zeros(1, dtype=ends.dtype, device=dev)).cpu().tolist()  # the one host sync
+        T = [int(v) for v in T]
+        st = Segments(T, dev)
+        st4 = st.scaled(4)
+        # 2. pitch / energy (pe_text_encoder -> pe_text_style_encoder -> PitchEnergyPredictor)
+        pe_enc = eng.text_encoder(2, sp, toks)
+        pe_style = eng.text_style(2, sp, pe_enc)
+        f0, en = eng.pitch_energy(sp, st, dur, pe_enc, pe_style)
+        # 3. speech predictor front (text_encoder, style_encoder, length regulator, x4 upsampling)
+        enc = eng.text_encoder(1, sp, toks)
+        style = eng.text_style(1, sp, enc)
+        asr = eng.length_regulate(sp, st4, dur, 4, enc, self.cfg.inter_dim)
+        p4, e4 = eng.upsample4(st, st4, f0), eng.upsample4(st, st4, en)
+        # 4. frame path
+        R = st4.rows
+        if noise is None:
+            noise = dict(prior_noise=torch.randn(R, 128, device=dev), src_noise=torch.randn(R * 75, device=dev),
+                         init_phase=torch.rand(1, device=dev))
+        audio = eng.frame_path(st4, asr, p4, e4, style, noise["prior_noise"], noise["src_noise"], noise["init_phase"], batch_scope=False)
+        eng.check_status()
+        waves = [audio[75 * int(st4.host[i]) : 75 * int(st4.host[i + 1])] for i in range(len(L))]
+        if return_details:
+            return waves, dict(durations=dur, frames=T, pitch=f0, energy=en, style=style)
+        return waves

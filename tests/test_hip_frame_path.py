@@ -64,9 +64,13 @@ def segs(lengths):
     [
         (128, 64, 1, 1, [64], 0),
         (130, 512, 3, 1, [64], 0),
-        (578, 512, 3, 1, [200, 37, 129], 1),
         (578, 512, 3, 1, [200, 37, 129], 2),
         (578, 512, 3, 1, [200, 37, 129], 3),
+        (578, 512, 3, 1, [200, 37, 129], 5),
+        (578, 512, 3, 1, [200, 37, 129], 6),
+        (578, 512, 3, 1, [200, 37, 129], 8),
+        (578, 512, 3, 1, [200, 37, 129], 11),
+        (96, 1025, 7, 1, [50, 333], 13),
         (128, 256, 5, 1, [96, 96], 0),
         (96, 1025, 7, 1, [50], 0),
         (64, 130, 7, 3, [77, 5], 0),

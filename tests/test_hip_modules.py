@@ -155,3 +155,37 @@ def test_export_model_end_to_end(mods):
     g2["durations"] = g["duration"].astype(np.int32)
     a2, _, _ = _staged_speech(mods["speech_predictor"].engine, g2, "export", 1)
     close(a2.reshape(-1), g["audio"], atol=1e-3, what="export waveform (teacher-forced pitch)")
+
+
+def test_synthesizer_matches_the_module_composition(mods, weights, cfg):
+    """pipeline.Synthesizer (packed ragged batch, one pass) == DurationPredictor -> DurationProcessor -> ExportModel per
+    utterance with the same noise (bit-identical: same kernels, utterances are independent)."""
+    from stylish_tts_amd import modules, synth
+    from stylish_tts_amd.pipeline import Synthesizer
+
+    eng = mods["speech_predictor"].engine
+    for m in mods.values():
+        m.engine  # bind every module's weights into the shared context
+    syn = Synthesizer(eng)
+    toks = [synth.tokens("syn.a", 1, 14, 178)[0].tolist(), synth.tokens("syn.b", 1, 9, 178)[0].tolist()]
+    # first pass to learn the predicted frame counts, then fixed noise for both paths
+    _, det = syn(toks, return_details=True)
+    T = det["frames"]
+    R4 = 4 * sum(T)
+    noise = dict(prior_noise=dev(synth.normal("syn.pn", (R4, 128))), src_noise=dev(synth.normal("syn.sn", (R4 * 75,))),
+                 init_phase=dev(synth.uniform("syn.ph", (1,))))
+    waves, det = syn(toks, noise=noise, return_details=True)
+    assert [w.numel() for w in waves] == [300 * t for t in T]
+    em = modules.ExportModel(device="cuda", **mods)
+    proc = modules.DurationProcessor(16, 50)
+    off = 0
+    for i, t in enumerate(toks):
+        texts, lens = dev(np.array([t], np.int64)), dev(np.array([len(t)], np.int64))
+        al = proc(mods["duration_predictor"](texts, lens)[0], len(t)).unsqueeze(0)
+        assert al.shape[2] == T[i]
+        r4 = 4 * T[i]
+        nz = dict(prior_noise=noise["prior_noise"][off : off + r4].t().unsqueeze(0), src_noise=noise["src_noise"][75 * off : 75 * (off + r4)].reshape(1, 1, -1),
+                  init_phase=noise["init_phase"].reshape(1, 1))
+        ref = em(texts, lens, al, noise=nz)
+        assert torch.equal(ref, waves[i]), float((ref - waves[i]).abs().max())
+        off += r4

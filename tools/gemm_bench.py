@@ -15,7 +15,7 @@ shapes = [  # name, cin, cout, k
 ]
 B, T4 = int(os.environ.get("B", 8)), 960
 flt = os.environ.get("SHAPES")
-tiles = [int(t) for t in os.environ.get("TILES", "1,2,3").split(",")]
+tiles = [int(t) for t in os.environ.get("TILES", "2,5,6").split(",")]
 for name, cin, cout, k in shapes:
     if flt and not any(f in name for f in flt.split(",")):
         continue
