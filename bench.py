@@ -105,11 +105,30 @@ def main():
     audio = torch.empty(BATCH * T4 * 75, dtype=torch.float32, device=device)
     gathered = [torch.empty_like(audio) for _ in range(world)] if (world > 1 and rank == 0) else None
 
+    collect = {"mode": "gather"}
+    all_buf = torch.empty(world * audio.numel(), dtype=torch.float32, device=device) if world > 1 else None
+
     def step():
         model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
                          batch_scope=True, out=audio)
         if world > 1:
-            dist.gather(audio, gathered, dst=0)  # waveforms to rank 0 over xGMI
+            if collect["mode"] == "gather":
+                dist.gather(audio, gathered, dst=0)  # waveforms to rank 0 over xGMI
+            else:
+                dist.all_gather_into_tensor(all_buf, audio)
+
+    if world > 1:
+        # pick the collective once, outside the timed region: gather (rank 0 receives) unless this RCCL build lacks it
+        ok = torch.ones(1, device=device)
+        try:
+            dist.gather(audio, gathered, dst=0)
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            ok.zero_()
+            print(f"[bench] rank {rank}: dist.gather unavailable ({e}); using all_gather_into_tensor", file=sys.stderr)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1:
+            collect["mode"] = "all_gather"
 
     for _ in range(args.warmup):
         step()
