@@ -20,6 +20,7 @@
 // Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
 // epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -53,6 +54,9 @@ struct GemmArgs {
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
   const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
+  int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
+  float* partial;         // [ksplit][rows_total][ld_part] raw partial sums (EPI_STORE only; splitk_reduce_kernel finishes)
+  int ld_part;
   int N;               // output channels actually stored (paired epilogues: channels of the result)
   const float* bias;   // [Npad] in packed row order, may be null
   // EPI_STORE
@@ -116,7 +120,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     by = (id / gx) % gy;
     bz = id / (gx * gy);
   }
-  const int utt = bz;
+  const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  const int utt = bz / ksplit, ks = bz % ksplit;
   const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
   const int row0 = lo + by * BN;
   if (row0 >= hi) return;
@@ -221,6 +226,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   int total = a.seg[0].ntaps * (a.seg[0].kc / 32);
   if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / 32);
   if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / 32);
+  if (ksplit > 1) {  // block-level split-K (single segment, enforced by the launcher): this block's slice of the iterations
+    const int it0 = (int)((long)total * ks / ksplit), it1 = (int)((long)total * (ks + 1) / ksplit);
+    chunk = it0 / g_ntaps;
+    tap = it0 % g_ntaps;
+    total = it1 - it0;
+  }
 
   const int l31 = lane & 31, lh = lane >> 5;
   auto mma_step = [&](const f32x4* Xs, const f32x4* Ws, int kk) {
@@ -369,6 +380,21 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // acc[i][j][r]: row = wn*WR + i*32 + (r&3) + 8*(r>>2) + 4*lh ; col = wm*WC + j*32 + l31
   const int nvalid = hi - row0;  // rows of this tile inside the utterance
   if constexpr (EPI == EPI_STORE) {
+    if (ksplit > 1) {
+      float* P = a.partial + (long)ks * a.rows_total * a.ld_part;
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        const int n = m0 + wm * WC + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wn * WR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (rl < nvalid) P[(long)(row0 + rl) * a.ld_part + n] = acc[i][j][r];
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
       const int n = m0 + wm * WC + j * 32 + l31;
@@ -464,6 +490,45 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   }
 }
 
+// Finishes a block-level split-K contraction: Y = (act(sum_ks partial[ks] + bias) [+ R]) * alpha, partials summed in a
+// fixed order (deterministic).  One thread per (row, 4 columns).
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int rows, int ld_part, int N,
+                                                            const float* __restrict__ bias, int act, const float* __restrict__ R, int ldr,
+                                                            int rcol0, float alpha, float* __restrict__ Y, int ldy, int ycol0) {
+  const int n4 = (N + 3) / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows * n4; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / n4), n = (int)(i % n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)row * ld_part + n);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(partial + ((long)k * rows + row) * ld_part + n);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (n + c < N) {
+        float x = act_apply(v[c] + (bias ? bias[n + c] : 0.0f), act);
+        if (R) x += R[(long)row * ldr + rcol0 + n + c];
+        Y[(long)row * ldy + ycol0 + n + c] = x * alpha;
+      }
+    }
+  }
+}
+
+// grow-only scratch for split-K partial sums (one per process = per GPU)
+inline float* splitk_scratch(size_t bytes) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(buf);
+    }
+    cap = bytes + bytes / 2;
+    if (hipMalloc(&buf, cap) != hipSuccess) {
+      buf = nullptr;
+      cap = 0;
+    }
+  }
+  return buf;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
@@ -508,7 +573,7 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows) {
-  dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt), block(WM * WN * 64 * KS);
+  dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
   switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL>), grid, block, 0, st, a); break;
     case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL>), grid, block, 0, st, a); break;
@@ -538,16 +603,39 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   if (tile == 0) tile = blocks128 >= 200 ? (paired ? 2 : 5) : (blocks128 >= 24 ? (paired ? 2 : 6) : 3);
   // (intra-block K-split, tiles 8-10, and 2-wave tiles measured no better than these at any layer shape: every
   //  configuration plateaus at ~80 % matrix-pipe occupancy)
+  // Block-level split-K for launches that cannot fill the chip (phoneme-rate layers, B = 1): one wave's MFMA chain over
+  // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
+  GemmArgs as = a;
+  as.ksplit = 1;
+  if (force_tile == 0 && epi == EPI_STORE && a.nseg == 1 && !a.sumsq_part && a.seg[0].w_utt_stride == 0) {
+    const int bn = tile == 5 ? 128 : (tile == 3 ? 32 : 64);
+    const long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
+    const int iters = a.seg[0].ntaps * (a.seg[0].kc / 32);
+    int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, 512 / std::max<long>(blocks, 1)));
+    if (ksp >= 2) {
+      float* part = splitk_scratch((size_t)ksp * a.rows_total * npad * sizeof(float));
+      if (part) {
+        as.ksplit = ksp;
+        as.partial = part;
+        as.ld_part = npad;
+      }
+    }
+  }
   GemmProfiler& prof = gemm_profiler();
   if (prof.on) (void)hipEventRecord(prof.next(), st);
   switch (tile) {
-    case 2: launch_cfg<128, 64, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;
-    case 5: launch_cfg<128, 128, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;    // 8 waves per block
-    case 6: launch_cfg<128, 64, 4, 2>(st, a, epi, npad, n_utt, max_rows); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
-    case 11: launch_cfg<128, 128, 4, 2, 1, true>(st, a, epi, npad, n_utt, max_rows); break;  // LDS-DMA staging, 8 waves
-    case 13: launch_cfg<128, 64, 4, 2, 1, true>(st, a, epi, npad, n_utt, max_rows); break;   // LDS-DMA staging, 64-row tile
-    case 8: launch_cfg<128, 128, 4, 2, 2>(st, a, epi, npad, n_utt, max_rows); break;  // 16 waves: 8 positions x 2 K-groups
-    default: launch_cfg<128, 32, 2, 1>(st, a, epi, npad, n_utt, max_rows); break;
+    case 2: launch_cfg<128, 64, 2, 2>(st, as, epi, npad, n_utt, max_rows); break;
+    case 5: launch_cfg<128, 128, 4, 2>(st, as, epi, npad, n_utt, max_rows); break;    // 8 waves per block
+    case 6: launch_cfg<128, 64, 4, 2>(st, as, epi, npad, n_utt, max_rows); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
+    case 11: launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows); break;  // LDS-DMA staging, 8 waves
+    case 13: launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows); break;   // LDS-DMA staging, 64-row tile
+    case 8: launch_cfg<128, 128, 4, 2, 2>(st, as, epi, npad, n_utt, max_rows); break;  // 16 waves: 8 positions x 2 K-groups
+    default: launch_cfg<128, 32, 2, 1>(st, as, epi, npad, n_utt, max_rows); break;
+  }
+  if (as.ksplit > 1) {
+    const long work = (long)a.rows_total * ((a.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), 0, st, as.partial, as.ksplit,
+                       a.rows_total, as.ld_part, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha, a.Y, a.ldy, a.ycol0);
   }
   if (prof.on) {
     (void)hipEventRecord(prof.next(), st);

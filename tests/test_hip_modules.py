@@ -159,7 +159,7 @@ def test_export_model_end_to_end(mods):
 
 def test_synthesizer_matches_the_module_composition(mods, weights, cfg):
     """pipeline.Synthesizer (packed ragged batch, one pass) == DurationPredictor -> DurationProcessor -> ExportModel per
-    utterance with the same noise (bit-identical: same kernels, utterances are independent)."""
+    utterance with the same noise (same kernels, utterances are independent)."""
     from stylish_tts_amd import modules, synth
     from stylish_tts_amd.pipeline import Synthesizer
 
@@ -187,5 +187,6 @@ def test_synthesizer_matches_the_module_composition(mods, weights, cfg):
         nz = dict(prior_noise=noise["prior_noise"][off : off + r4].t().unsqueeze(0), src_noise=noise["src_noise"][75 * off : 75 * (off + r4)].reshape(1, 1, -1),
                   init_phase=noise["init_phase"].reshape(1, 1))
         ref = em(texts, lens, al, noise=nz)
-        assert torch.equal(ref, waves[i]), float((ref - waves[i]).abs().max())
+        # same kernels; only the split-K factor (hence the fp32 summation order) may differ between batch shapes
+        assert float((ref - waves[i]).abs().max()) < 5e-5
         off += r4

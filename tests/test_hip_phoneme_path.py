@@ -75,7 +75,9 @@ def test_ragged_batch_is_per_utterance(hip):
     close(logits.cpu().numpy()[: L[0]], g["logits"][0], what="logits utt0")
     s1 = segs([L[1]])
     l1, d1 = hip.duration(s1, dev(toks[L[0] :]))
-    assert torch.equal(l1, logits[L[0] :]) and torch.equal(d1, dur[L[0] :])
+    # the launcher may cut K differently for different batch shapes (split-K): same math, fp32 summation order only
+    close(l1.cpu().numpy(), logits[L[0] :].cpu().numpy(), rtol=2e-5, what="packed == single-utterance run")
+    assert torch.equal(d1, dur[L[0] :])
 
 
 def test_duration_decode_both_branches(hip):
