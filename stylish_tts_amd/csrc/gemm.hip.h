@@ -226,11 +226,24 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   int total = a.seg[0].ntaps * (a.seg[0].kc / 32);
   if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / 32);
   if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / 32);
-  if (ksplit > 1) {  // block-level split-K (single segment, enforced by the launcher): this block's slice of the iterations
-    const int it0 = (int)((long)total * ks / ksplit), it1 = (int)((long)total * (ks + 1) / ksplit);
+  if (ksplit > 1) {  // block-level split-K: this block's slice [it0, it1) of the iterations; position the cursor at it0
+    int it0 = (int)((long)total * ks / ksplit);
+    const int it1 = (int)((long)total * (ks + 1) / ksplit);
+    total = it1 - it0;
+    for (int q = 0; q < 2; ++q) {  // skip whole segments (at most two)
+      const int n_it = g_ntaps * (g_kc / 32);
+      if (it0 >= n_it && s + 1 < nseg) {
+        it0 -= n_it;
+        ++s;
+        const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
+        gX = n.X + n.xcol0;
+        gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+        g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+        seg_offsets();
+      }
+    }
     chunk = it0 / g_ntaps;
     tap = it0 % g_ntaps;
-    total = it1 - it0;
   }
 
   const int l31 = lane & 31, lh = lane >> 5;
@@ -607,10 +620,11 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
   GemmArgs as = a;
   as.ksplit = 1;
-  if (force_tile == 0 && epi == EPI_STORE && a.nseg == 1 && !a.sumsq_part && a.seg[0].w_utt_stride == 0) {
+  if (force_tile == 0 && epi == EPI_STORE && !a.sumsq_part) {
     const int bn = tile == 5 ? 128 : (tile == 3 ? 32 : 64);
     const long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
-    const int iters = a.seg[0].ntaps * (a.seg[0].kc / 32);
+    int iters = 0;
+    for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
     int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, 512 / std::max<long>(blocks, 1)));
     if (ksp >= 2) {
       float* part = splitk_scratch((size_t)ksp * a.rows_total * npad * sizeof(float));
