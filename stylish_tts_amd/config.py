@@ -88,6 +88,13 @@ DEFAULT_MODEL = {
         "last_dropout": 0.5,
     },
     "pitch_energy_predictor": {"inter_dim": 256, "dropout": 0.2},
+    # text symbols (model.yml:81-85); index = position in pad + punctuation + letters + letters_ipa
+    "symbol": {
+        "pad": '$',
+        "punctuation": ';:,.!?¡¿—…"()“” ',
+        "letters": 'ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz',
+        "letters_ipa": "ɑɐɒæɓʙβɔɕçɗɖðʤəɘɚɛɜɝɞɟʄɡɠɢʛɦɧħɥʜɨɪʝɭɬɫɮʟɱɯɰŋɳɲɴøɵɸθœɶʘɹɺɾɻʀʁɽʂʃʈʧʉʊʋⱱʌɣɤʍχʎʏʑʐʒʔʡʕʢǀǁᵊǃˈˌːˑʼʴʰʱʲʷˠˤ˞↓↑→↗↘'̩'ᵻ",
+    },
 }
 
 

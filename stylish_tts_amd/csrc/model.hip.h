@@ -623,7 +623,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       w.n_rs = L.rs[i].N; w.out_acc = i > 0;
       GemmProfiler& prof = gemm_profiler();
       if (prof.on) (void)hipEventRecord(prof.next(), st);
-      hipLaunchKernelGGL(wn_layer_kernel, dim3(ceil_div(ml, 32), s.n_utt), dim3(512), 0, st, w);
+      hipLaunchKernelGGL(wn_layer_kernel<4>, dim3(ceil_div(ml, 32), s.n_utt), dim3(1024), 0, st, w);
       if (prof.on) {
         (void)hipEventRecord(prof.next(), st);
         prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh));

@@ -7,8 +7,11 @@
 // and two launches per layer for 3 GFLOP.  Here a block owns 32 time rows x all 256 gate columns, so the gated
 // activations never leave the CU: phase 1 contracts K = 5 taps x 128 channels from HBM/L2 tiles, the gate epilogue
 // writes acts [32 x 128] into LDS, phase 2 contracts K = 128 with the A operand read straight from LDS, and the
-// epilogue updates h / out.  8 waves per block = 4 column groups x 2 K-groups (the K-groups split every 32-channel
-// chunk in halves and are summed through LDS), i.e. two waves per SIMD that cover each other's staging.
+// epilogue updates h / out.  KG = 4: 16 waves per block = 4 column groups x 4 K-groups (each K-group takes a quarter of
+// every 32-channel chunk; partial sums are exchanged through LDS in two halving steps), four waves per SIMD.
+// Measured with in-kernel timestamps (B = 8, 35.5 us per launch): 24 K-iterations at 1.17 us = 28 us, i.e. ~80 % of the
+// MFMA issue limit (2048 cycles per iteration per SIMD); prologue 2 us, exchange + gate 3 us, everything else 1.5 us.
+// The operands of both epilogues (bias, gate, h / out values) are requested before the loops that precede them.
 // h is double buffered (Hin -> Hout): neighbouring blocks still read this block's Hin rows as their conv halo.
 #pragma once
 #include <type_traits>
@@ -32,8 +35,10 @@ struct WnArgs {
   int out_acc;         // accumulate into Out (0 on the first layer: output = zeros + ...)
 };
 
-__global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
+template <int KG>  // K-groups per block: 2 (8 waves) or 4 (16 waves, four per SIMD)
+__global__ void __launch_bounds__(256 * KG) wn_layer_kernel(const WnArgs a) {
   constexpr int RT = 32, C = 128, NG = 256, TAPS = 5, PAD = 2;
+  constexpr int NT = 256 * KG, WPT = 2048 / NT, KEEP = 16 / KG;  // threads, W f32x4 per thread per tile, accumulator rows a wave finishes
   constexpr int STG = (RT + NG) * 8;  // f32x4 per staging buffer
   __shared__ f32x4 stage[2 * STG];    // 73,728 B
   __shared__ f32x4 acts[RT * 32];     // 16 KB: [32-channel chunk][row][8 slots], same swizzle as the staging tiles
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
   // ahead: iteration `it` computes tile it from buffer it&1, stores tile it+1 (fetched during it-2) and fetches tile it+3.
   // two explicit register sets (named, not an array indexed by the set: that would be demoted to LDS/scratch)
   struct RegSet {
-    f32x4 x, w[4];
+    f32x4 x, w[WPT];
     bool ok;
   };
   RegSet rs0, rs1;
@@ -75,8 +80,8 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
       rs.ok = ok;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 512;
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * NT;
       const int n = idx >> 3, sl = idx & 7;
       rs.w[i] = *reinterpret_cast<const f32x4*>(a.Win + ((long)n * TAPS + tap) * C + chunk * 32 + sl * 4);
     }
@@ -90,8 +95,8 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
       Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = rs.ok ? rs.x : z;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 512;
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * NT;
       const int n = idx >> 3, sl = idx & 7;
       Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = rs.w[i];
     }
@@ -110,46 +115,74 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
   };
   // exchange between the two K-groups: each group keeps the half of the 16 accumulator rows it will finish
   // (kg 0: r < 8, kg 1: r >= 8) and hands the other half over through LDS.
-  float* red = reinterpret_cast<float*>(stage);  // [wc][j][r][lane] : 4 * 2 * 16 * 64 floats = 32 KB
+  float* red = reinterpret_cast<float*>(stage);  // [kg][wc][j][8][lane] : KG * 4 * 2 * 8 * 64 floats = 32 / 64 KB
   // Accumulator registers must only ever be indexed by compile-time constants (a run-time index demotes the vector
   // to memory, and the compiler even re-merges two static branches into one dynamic loop).  So K-group 1 first swaps
   // its register halves with conditional moves; afterwards BOTH groups finish registers 0..7 and hand over 8..15,
   // and only the logical row number (an ordinary integer) depends on the group: ro = r + 8*kg resp. r - 8*kg.
   auto exchange = [&]() {
+    const int k0 = kg & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const float lo8 = acc[j][r], hi8 = acc[j][r + 8];
-        acc[j][r] = kg ? hi8 : lo8;
-        acc[j][r + 8] = kg ? lo8 : hi8;
+        acc[j][r] = k0 ? hi8 : lo8;
+        acc[j][r + 8] = k0 ? lo8 : hi8;
       }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 8; r < 16; ++r) red[((wc * 2 + j) * 16 + (r - 8 * kg)) * 64 + lane] = acc[j][r];
+      for (int r = 8; r < 16; ++r) red[(((kg * 4 + wc) * 2 + j) * 8 + (r - 8)) * 64 + lane] = acc[j][r];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[j][r] += red[((wc * 2 + j) * 16 + (r + 8 * kg)) * 64 + lane];
+      for (int r = 0; r < 8; ++r) acc[j][r] += red[((((kg ^ 1) * 4 + wc) * 2 + j) * 8 + r) * 64 + lane];
+    if constexpr (KG == 4) {  // second level: partner kg ^ 2, quarters of the 16 rows
+      const int k1 = kg >> 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float lo4 = acc[j][r], hi4 = acc[j][r + 4];
+          acc[j][r] = k1 ? hi4 : lo4;
+          acc[j][r + 4] = k1 ? lo4 : hi4;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 4; r < 8; ++r) red[(((kg * 4 + wc) * 2 + j) * 8 + (r - 4)) * 64 + lane] = acc[j][r];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] += red[((((kg ^ 2) * 4 + wc) * 2 + j) * 8 + r) * 64 + lane];
+    }
   };
+  // logical accumulator row of register r (< KEEP) after the exchange
+  auto logical_row = [&](int r) { return KG == 4 ? r + 4 * (kg >> 1) + 8 * (kg & 1) : r + 8 * kg; };
 
   gload1(rs0, 0);
   lstore(rs0, 0, true);
   gload1(rs1, 1);
   gload1(rs0, 2);
+  // operands of the gate epilogue, fetched behind the first tiles so their latency is hidden by the loop
+  const int ch = wc * 32 + l31;  // activation channel of this lane
+  const float ba = a.bin[wc * 64 + l31], bb = a.bin[wc * 64 + 32 + l31];
+  const float ga = a.gate[(long)utt * a.ld_gate + a.gcol0 + ch], gb = a.gate[(long)utt * a.ld_gate + a.gcol0 + C + ch];
   __syncthreads();
   auto iter1 = [&](int it, RegSet& nset) {  // nset: register set holding tile it+1
     const f32x4* Xs = stage + (it & 1) * STG;
     const f32x4* Ws = Xs + RT * 8;
     {
-      const int kk = 2 * kg, slot = 2 * kk + lh;
+      const int kk = (4 / KG) * kg, slot = 2 * kk + lh;
       mma(Xs[l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
     lstore(nset, (it + 1) & 1, true);
-    gload1(nset, it + 3);
-    {
+    if (it + 3 < TAPS * 4) gload1(nset, it + 3);  // no dummy fetches at the tail: the next phase reuses the registers
+    if constexpr (KG == 2) {
       const int kk = 2 * kg + 1, slot = 2 * kk + lh;
       mma(Xs[l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
@@ -160,21 +193,52 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
     iter1(it + 1, rs0);
   }
 
+  // phase-2 operands are requested now, before the exchange and the gate math: the first two res/skip weight tiles
+  // and the h / out values the final epilogue updates.
+  const bool col_active = wc * 64 < a.n_rs;  // last layer: only 128 output columns
+  auto gload2 = [&](RegSet& rs, int chunk) {
+    chunk = min(chunk, 3);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * NT;
+      const int n = idx >> 3, sl = idx & 7;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rs.w[i] = n < a.n_rs ? *reinterpret_cast<const f32x4*>(a.Wrs + (long)n * C + chunk * 32 + sl * 4) : z;
+    }
+  };
+  gload2(rs0, 0);
+  gload2(rs1, 1);
+  const int nvalid = hi - row0;
+  const bool wide = a.n_rs == 2 * C;  // 256-wide res/skip: first half goes to h, the rest to out
+  float bv[2], old[2][KEEP];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = wc * 64 + j * 32 + l31;
+    bv[j] = col_active ? a.brs[n] : 0.0f;
+    const bool to_h = wide && n < C;
+    const int col = (wide && n >= C) ? n - C : n;
+    const float* src = to_h ? a.Hin : a.Out;
+#pragma unroll
+    for (int r = 0; r < KEEP; ++r) {
+      const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
+      old[j][r] = (col_active && row < nvalid && (to_h || a.out_acc)) ? src[(long)(row0 + row) * C + col] : 0.0f;
+    }
+  }
+
   exchange();
   {
-    const int ch = wc * 32 + l31;  // activation channel of this lane
-    const float ba = a.bin[wc * 64 + l31], bb = a.bin[wc * 64 + 32 + l31];
-    const float ga = a.gate[(long)utt * a.ld_gate + a.gcol0 + ch], gb = a.gate[(long)utt * a.ld_gate + a.gcol0 + C + ch];
     float* af = reinterpret_cast<float*>(acts);
     const int chunk = ch >> 5, slot = (ch >> 2) & 7;
     auto gate_one = [&](float xa, float xb, int r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float va = xa + ba + ga, vb = xb + bb + gb;
-      const float th = 1.0f - 2.0f / (__expf(2.0f * va) + 1.0f);  // tanh
-      af[(chunk * (RT * 8) + row * 8 + (slot ^ ((row >> 1) & 7))) * 4 + (ch & 3)] = th * (1.0f / (1.0f + __expf(-vb)));
+      // tanh(va) * sigmoid(vb) with hardware exp2 / rcp (1 ulp each): 16 waves share four VALUs here, and IEEE
+      // division sequences made this epilogue cost more than an MFMA iteration
+      const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.885390082f * va) + 1.0f);
+      af[(chunk * (RT * 8) + row * 8 + (slot ^ ((row >> 1) & 7))) * 4 + (ch & 3)] = th * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * vb));
     };
 #pragma unroll
-    for (int r = 0; r < 8; ++r) gate_one(acc[0][r], acc[1][r], r + 8 * kg);
+    for (int r = 0; r < KEEP; ++r) gate_one(acc[0][r], acc[1][r], logical_row(r));
   }
   __syncthreads();
 
@@ -183,33 +247,22 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-  const bool col_active = wc * 64 < a.n_rs;  // last layer: only 128 output columns
-  auto gload2 = [&](RegSet& rs, int chunk) {
-    chunk = min(chunk, 3);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 512;
-      const int n = idx >> 3, sl = idx & 7;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      rs.w[i] = n < a.n_rs ? *reinterpret_cast<const f32x4*>(a.Wrs + (long)n * C + chunk * 32 + sl * 4) : z;
-    }
-  };
-  gload2(rs0, 0);
   lstore(rs0, 0, false);
-  gload2(rs1, 1);
   gload2(rs0, 2);
   __syncthreads();
   auto iter2 = [&](int it, RegSet& nset) {
     const f32x4* Ws = stage + (it & 1) * STG + RT * 8;
     if (col_active) {
-      const int kk = 2 * kg, slot = 2 * kk + lh;
+      const int kk = (4 / KG) * kg, slot = 2 * kk + lh;
       mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
     }
     lstore(nset, (it + 1) & 1, false);
-    gload2(nset, it + 3);
-    if (col_active) {
-      const int kk = 2 * kg + 1, slot = 2 * kk + lh;
-      mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+    if (it + 3 < 4) gload2(nset, it + 3);
+    if constexpr (KG == 2) {
+      if (col_active) {
+        const int kk = 2 * kg + 1, slot = 2 * kk + lh;
+        mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+      }
     }
     __syncthreads();
   };
@@ -219,27 +272,17 @@ __global__ void __launch_bounds__(512) wn_layer_kernel(const WnArgs a) {
   }
   exchange();
   if (col_active) {
-    const int nvalid = hi - row0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = wc * 64 + j * 32 + l31;
-      const float bv = a.brs[n];
-      const bool to_h = a.n_rs == 2 * C && n < C;  // first half of a 256-wide res/skip goes to h, the rest to out
-      const int col = (a.n_rs == 2 * C && n >= C) ? n - C : n;
-      auto put = [&](float x, int r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < nvalid) {
-          const long g = (long)(row0 + row) * C + col;
-          const float v = x + bv;
-          if (to_h) {
-            a.Hout[g] = a.Hin[g] + v;
-          } else {
-            a.Out[g] = a.out_acc ? a.Out[g] + v : v;
-          }
-        }
-      };
+      const bool to_h = wide && n < C;
+      const int col = (wide && n >= C) ? n - C : n;
+      float* dst = to_h ? a.Hout : a.Out;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) put(acc[j][r], r + 8 * kg);
+      for (int r = 0; r < KEEP; ++r) {
+        const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
+        if (row < nvalid) dst[(long)(row0 + row) * C + col] = old[j][r] + (acc[j][r] + bv[j]);
+      }
     }
   }
 }

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from .runtime import HipModel, Segments
+from .text import TextCleaner, frame_tokens, to_int16, write_wav
 
 
 class Synthesizer:
@@ -22,6 +23,24 @@ class Synthesizer:
     def __init__(self, engine: HipModel):
         self.eng = engine
         self.cfg = engine.cfg
+        self.text_cleaner = TextCleaner(self.cfg.symbol) if "symbol" in self.cfg else None
+
+    def infer(self, texts: Sequence[str], noise: Optional[Dict[str, torch.Tensor]] = None, out_prefix: Optional[str] = None, combine: bool = False):
+        """Phoneme strings → int16 waveforms, all utterances in one pass (the loop body of ``train/test_onnx.py:48-90``).
+
+        With ``out_prefix`` the samples are also written as ``<prefix>_<i>.wav`` (or ``<prefix>_combined.wav``).
+        """
+        if self.text_cleaner is None:
+            raise ValueError("model config has no 'symbol' section")
+        waves = self([frame_tokens(self.text_cleaner(t)) for t in texts], noise=noise)
+        samples = [to_int16(w) for w in waves]
+        if out_prefix is not None:
+            if combine:
+                write_wav(f"{out_prefix}_combined.wav", np.concatenate(samples, axis=-1), self.cfg.sample_rate)
+            else:
+                for i, smp in enumerate(samples):
+                    write_wav(f"{out_prefix}_{i}.wav", smp, self.cfg.sample_rate)
+        return samples
 
     @torch.no_grad()
     def __call__(self, token_lists: Sequence[Sequence[int]], noise: Optional[Dict[str, torch.Tensor]] = None, return_details: bool = False):

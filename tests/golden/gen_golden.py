@@ -397,5 +397,36 @@ def main():
     save("mrf_block", x=xm, style=style, y=ym, **meta)
 
 
+def text_golden():
+    """Tokeniser and wav-writer vectors (lib/text_utils.py:8-41, train/test_onnx.py:49-53,79-90)."""
+    import io, json
+    from scipy.io.wavfile import write
+    from stylish_tts.lib.text_utils import TextCleaner
+
+    mc = load_model_config_yaml(open(os.path.join(REF_SRC, "stylish_tts/train/config/model.yml")))
+    tc = TextCleaner(mc.symbol)
+    texts = [
+        "ðə kwˈɪk bɹˈaʊn fˈɑːks dʒˈʌmps ˌoʊvɚ ðə lˈeɪzi dˈɑːɡ.",
+        "hɛlˈoʊ, wˈɜːld! — “kwˈoʊt” (ænd) mˈɔːɹ…",
+        "'ᵻ' ǀǁᵊǃ ↓↑→↗↘ $",
+        "unknown: @#%^ 123 stays out",
+        "",
+    ]
+    ids = [tc(x) for x in texts]
+    rng = np.random.default_rng(SEED)
+    wave = np.tanh(rng.standard_normal(1234).astype(np.float32))
+    pcm = np.multiply(wave, 32768).astype(np.int16)
+    buf = io.BytesIO()
+    write(buf, 24000, pcm)
+    path = os.path.join(HERE, "text_tokens.json")
+    json.dump(dict(texts=texts, ids=ids, table_size=len(tc.word_index_dictionary), wave=wave.tolist(), pcm=pcm.tolist(),
+                   wav_hex=buf.getvalue().hex()), open(path, "w"), ensure_ascii=False)
+    print("  wrote text_tokens.json", os.path.getsize(path))
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-text" in sys.argv:
+        _ = text_golden()
+    else:
+        main()
+        text_golden()

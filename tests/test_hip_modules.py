@@ -15,6 +15,12 @@ def mods(cfg):
     return modules.build_inference_modules(cfg, synthetic_seed=0)
 
 
+def synth_normal(name, shape):
+    from stylish_tts_amd import synth
+
+    return synth.normal(name, shape)
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -190,3 +196,29 @@ def test_synthesizer_matches_the_module_composition(mods, weights, cfg):
         # same kernels; only the split-K factor (hence the fp32 summation order) may differ between batch shapes
         assert float((ref - waves[i]).abs().max()) < 5e-5
         off += r4
+
+
+def test_infer_from_phoneme_strings(mods, tmp_path):
+    """Synthesizer.infer: TextCleaner -> pad-framed tokens -> one packed pass -> int16 (train/test_onnx.py:48-90)."""
+    from stylish_tts_amd.pipeline import Synthesizer
+    from stylish_tts_amd.text import frame_tokens, to_int16
+
+    eng = mods["speech_predictor"].engine
+    for m in mods.values():
+        m.engine
+    syn = Synthesizer(eng)
+    texts = ["hɛlˈoʊ wˈɜːld.", "ðə kwˈɪk bɹˈaʊn fˈɑːks @ dʒˈʌmps!"]  # '@' is outside the table and is dropped
+    toks = [frame_tokens(syn.text_cleaner(t)) for t in texts]
+    assert toks[0][0] == 0 and toks[0][-1] == 0 and len(toks[1]) == len(texts[1]) - 1 + 2
+    _, det = syn(toks, return_details=True)
+    R4 = 4 * sum(det["frames"])
+    noise = dict(prior_noise=dev(synth_normal("inf.pn", (R4, 128))), src_noise=dev(synth_normal("inf.sn", (R4 * 75,))),
+                 init_phase=dev(np.array([0.25], np.float32)))
+    pcm = syn.infer(texts, noise=noise, out_prefix=str(tmp_path / "sample"))
+    waves = syn(toks, noise=noise)
+    for i, (p, w) in enumerate(zip(pcm, waves)):
+        assert p.dtype == np.int16 and p.shape[0] == 300 * det["frames"][i]
+        assert np.abs(p.astype(np.int32) - to_int16(w).astype(np.int32)).max() <= 1
+        from scipy.io import wavfile
+        rate, back = wavfile.read(str(tmp_path / f"sample_{i}.wav"))
+        assert rate == 24000 and np.array_equal(back, p)
