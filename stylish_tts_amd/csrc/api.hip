@@ -309,6 +309,8 @@ int stts_profile_end(void* stream, int* launches, double* total_ms, double* tota
     float t = 0;
     STTS_HIP(hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]));
     ms += t;
+    if (getenv("STTS_PROFILE_DUMP") && i / 2 < p.flops.size())  // per-launch list for tools/ (events include launch gaps)
+      fprintf(stderr, "launch %3zu  %8.1f us  %8.3f GFLOP  %6.1f TFLOP/s\n", i / 2, t * 1e3, p.flops[i / 2] * 1e-9, p.flops[i / 2] / (t * 1e-3) * 1e-12);
   }
   for (double f : p.flops) fl += f;
   if (launches) *launches = (int)(p.used / 2);

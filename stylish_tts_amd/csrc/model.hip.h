@@ -606,7 +606,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   for (int f = 7; f >= 0; --f) {
     const FlowLayerW& L = c->flow[f];
     const int p = f & 1;
-    {
+    if (f == 7) {  // later blocks get their `pre` from the tail of the previous block's last WaveNet launch
       GemmArgs a = gemm_args(s);
       set_seg(a, 0, z, fh, p * half, L.pre);
       a.N = fh; a.bias = L.pre.bias; a.Y = hf; a.ldy = fh;
@@ -615,26 +615,35 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     float* hcur = hf;
     float* hnext = hf2;
     for (int i = 0; i < 4; ++i) {
-      // one launch per WaveNet layer: conv k5 + gate + res/skip + h/out update (wn_layer.hip.h)
+      // one launch per WaveNet layer: conv k5 + gate + res/skip + h/out update (wn_layer.hip.h); the last one also
+      // applies the block's post projection + reverse coupling and the next block's pre projection to its rows
       WnArgs w;
       w.Hin = hcur; w.Hout = i < 3 ? hnext : nullptr; w.Out = outf; w.seg_off = s.dev;
       w.Win = L.in[i].W; w.bin = L.in[i].bias; w.Wrs = L.rs[i].W; w.brs = L.rs[i].bias;
       w.gate = cond; w.ld_gate = c->flow_style.ld(); w.gcol0 = L.cond_col0 + i * 2 * fh;
       w.n_rs = L.rs[i].N; w.out_acc = i > 0;
+      w.tail = 0; w.Wproj = w.bproj = w.Wpre = w.bpre = nullptr; w.Z = w.Hpre = nullptr; w.ldz = w.zcol0 = 0;
+      double extra = 0;
+      if (i == 3) {
+        w.tail = f > 0 ? 2 : 1;
+        w.Wproj = L.proj.W; w.bproj = L.proj.bias; w.Z = z; w.ldz = fh; w.zcol0 = (1 - p) * half;
+        extra = 2.0 * (double)R * fh * fh;
+        if (f > 0) {
+          const FlowLayerW& nx = c->flow[f - 1];
+          w.Wpre = nx.pre.W; w.bpre = nx.pre.bias; w.Hpre = hf;  // layer 3 reads hf2; hf is free and is the next block's h
+          extra += 2.0 * (double)R * fh * half;
+        }
+      }
       GemmProfiler& prof = gemm_profiler();
       if (prof.on) (void)hipEventRecord(prof.next(), st);
       hipLaunchKernelGGL(wn_layer_kernel<4>, dim3(ceil_div(ml, 32), s.n_utt), dim3(1024), 0, st, w);
       if (prof.on) {
         (void)hipEventRecord(prof.next(), st);
-        prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh));
+        prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh) + extra);
       }
       std::swap(hcur, hnext);
     }
     STTS_HIP(hipGetLastError());
-    GemmArgs q = gemm_args(s);
-    set_seg(q, 0, outf, fh, 0, L.proj);
-    q.N = half; q.bias = L.proj.bias; q.Z = z; q.ldz = fh; q.zcol0 = (1 - p) * half;
-    STTS_TRY(launch_conv_gemm(st, q, EPI_COUPLE, L.proj.npad, s.n_utt, ml));
   }
   if (z_flow_out) STTS_HIP(hipMemcpyAsync(z_flow_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
   GemmArgs a = gemm_args(s);

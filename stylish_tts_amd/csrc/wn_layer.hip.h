@@ -33,6 +33,17 @@ struct WnArgs {
   int ld_gate, gcol0;
   int n_rs;            // 256 (layers 0..n-2: h-part | out-part) or 128 (last layer: out only)
   int out_acc;         // accumulate into Out (0 on the first layer: output = zeros + ...)
+  // tail (last layer of a coupling block only): 0 = none; 1 = the block's `post` projection + reverse coupling
+  // (flow.py:199-211) on this tile's rows; 2 = additionally the NEXT coupling block's `pre` projection (flow.py:188-190),
+  // whose input is exactly the half just updated.  Both are 1x1 (no halo), so the 32-row tile is self-contained.
+  int tail;
+  const float* Wproj;  // packed paired [128][1][128]
+  const float* bproj;  // [128] packed order
+  float* Z;            // [rows, ldz]; columns [zcol0, zcol0 + 64) are updated in place
+  int ldz, zcol0;
+  const float* Wpre;   // packed plain [128][1][64]
+  const float* bpre;   // [128]
+  float* Hpre;         // [rows, 128]: h of the next coupling block
 };
 
 template <int KG>  // K-groups per block: 2 (8 waves) or 4 (16 waves, four per SIMD)
@@ -271,19 +282,123 @@ __global__ void __launch_bounds__(256 * KG) wn_layer_kernel(const WnArgs a) {
     iter2(it + 1, rs0);
   }
   exchange();
+  if (!a.tail) {
+    if (col_active) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wc * 64 + j * 32 + l31;
+        const bool to_h = wide && n < C;
+        const int col = (wide && n >= C) ? n - C : n;
+        float* dst = to_h ? a.Hout : a.Out;
+#pragma unroll
+        for (int r = 0; r < KEEP; ++r) {
+          const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
+          if (row < nvalid) dst[(long)(row0 + row) * C + col] = old[j][r] + (acc[j][r] + bv[j]);
+        }
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ tail: post projection + coupling (+ next pre)
+  // The finished `out` tile [32 x 128] goes to LDS (same chunked, swizzled layout as the gated activations) instead of
+  // HBM and is the A operand of the coupling projection; the updated half of z then feeds the next block's `pre`.
+  float* af = reinterpret_cast<float*>(acts);
+  auto act_put = [&](int row, int ch, float v) {
+    af[((ch >> 5) * (RT * 8) + row * 8 + (((ch >> 2) & 7) ^ ((row >> 1) & 7))) * 4 + (ch & 3)] = v;
+  };
+  auto gloadw = [&](RegSet& rs, const float* W, int kc, int chunk) {  // 128 packed columns x 32 channels
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * NT;
+      const int n = idx >> 3, sl = idx & 7;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rs.w[i] = n < C ? *reinterpret_cast<const f32x4*>(W + (long)n * kc + chunk * 32 + sl * 4) : z;
+    }
+  };
+  // contraction of the LDS tile in `acts` (NCH chunks of 32 channels) with W [128][kc]; all waves stage, column
+  // groups 0 and 1 multiply.  The caller has put a barrier between the last reader of `stage` and this call.
+  auto lds_gemm = [&](auto nch, const float* W, int kc) {
+    constexpr int NCH = decltype(nch)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    gloadw(rs0, W, kc, 0);
+    gloadw(rs1, W, kc, 1);
+    lstore(rs0, 0, false);
+    if constexpr (NCH > 2) gloadw(rs0, W, kc, 2);
+    __syncthreads();
+    auto step = [&](int it, RegSet& nset) {
+      const f32x4* Ws = stage + (it & 1) * STG + RT * 8;
+      if (wc < 2) {
+        const int kk = (4 / KG) * kg, slot = 2 * kk + lh;
+        mma(acts[it * (RT * 8) + l31 * 8 + (slot ^ ((l31 >> 1) & 7))], Ws, kk);
+        if constexpr (KG == 2) {
+          const int kk2 = 2 * kg + 1, slot2 = 2 * kk2 + lh;
+          mma(acts[it * (RT * 8) + l31 * 8 + (slot2 ^ ((l31 >> 1) & 7))], Ws, kk2);
+        }
+      }
+      if (it + 1 < NCH) lstore(nset, (it + 1) & 1, false);
+      if (it + 3 < NCH) gloadw(nset, W, kc, it + 3);
+      __syncthreads();
+    };
+#pragma unroll
+    for (int it = 0; it < NCH; it += 2) {
+      step(it, rs1);
+      step(it + 1, rs0);
+    }
+  };
   if (col_active) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = wc * 64 + j * 32 + l31;
-      const bool to_h = wide && n < C;
-      const int col = (wide && n >= C) ? n - C : n;
-      float* dst = to_h ? a.Hout : a.Out;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < KEEP; ++r) {
         const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
-        if (row < nvalid) dst[(long)(row0 + row) * C + col] = old[j][r] + (acc[j][r] + bv[j]);
+        act_put(row, wc * 64 + j * 32 + l31, old[j][r] + (acc[j][r] + bv[j]));
       }
+  }
+  // coupling operands, requested ahead of the projection
+  const int cc = (wc & 1) * 32 + l31;  // result channel of this lane (column groups 0, 1)
+  float pa = 0.f, pb = 0.f, zold[KEEP];
+  if (wc < 2) {
+    pa = a.bproj[wc * 64 + l31];
+    pb = a.bproj[wc * 64 + 32 + l31];
+  }
+#pragma unroll
+  for (int r = 0; r < KEEP; ++r) {
+    const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
+    zold[r] = (wc < 2 && row < nvalid) ? a.Z[(long)(row0 + row) * a.ldz + a.zcol0 + cc] : 0.0f;
+  }
+  __syncthreads();  // `out` tile complete; every wave is past the exchange that used `stage`
+  lds_gemm(std::integral_constant<int, 4>{}, a.Wproj, C);
+  exchange();
+  float hb[2] = {0.f, 0.f};
+  if (a.tail > 1 && wc < 2) {
+    hb[0] = a.bpre[wc * 64 + l31];
+    hb[1] = a.bpre[wc * 64 + 32 + l31];
+  }
+  if (wc < 2) {
+#pragma unroll
+    for (int r = 0; r < KEEP; ++r) {
+      const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
+      const float z1 = (zold[r] - (acc[0][r] + pa)) * __expf(-(acc[1][r] + pb));  // x1 = (x1 - m) * exp(-logs)
+      if (row < nvalid) a.Z[(long)(row0 + row) * a.ldz + a.zcol0 + cc] = z1;
+      act_put(row, cc, z1);  // every wave finished reading `acts` before the last barrier of lds_gemm
     }
+  }
+  if (a.tail < 2) return;
+  __syncthreads();
+  lds_gemm(std::integral_constant<int, 2>{}, a.Wpre, C / 2);
+  exchange();
+  if (wc < 2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < KEEP; ++r) {
+        const int ro = logical_row(r), row = (ro & 3) + 8 * (ro >> 2) + 4 * lh;
+        if (row < nvalid) a.Hpre[(long)(row0 + row) * C + wc * 64 + j * 32 + l31] = acc[j][r] + hb[j];
+      }
   }
 }
 
