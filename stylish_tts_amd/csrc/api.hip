@@ -477,7 +477,11 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   Seg s{n_utt, h.data(), so};
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, X, kc, 0, pc);
-  a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy; a.tune = tune;
+  a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy; a.tune = tune & 63;
+  long long* dbg = nullptr;
+  const size_t dbg_n = 8 * 16384;
+  if (tune & 64) { STTS_HIP(hipMalloc(&dbg, dbg_n * 8)); STTS_HIP(hipMemset(dbg, 0, dbg_n * 8)); }
+  a.dbg = dbg;
   hipEvent_t e0, e1;
   STTS_HIP(hipEventCreate(&e0));
   STTS_HIP(hipEventCreate(&e1));
@@ -489,6 +493,76 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   float ms = 0;
   STTS_HIP(hipEventElapsedTime(&ms, e0, e1));
   *avg_ms = ms / iters;
+  if (dbg) {
+    std::vector<long long> hdb(dbg_n);
+    STTS_HIP(hipMemcpy(hdb.data(), dbg, dbg_n * 8, hipMemcpyDeviceToHost));
+    // per-block records of the LAST launch: [t0, t1, t2, t3, iters, hw_id, xcc_id, -]
+    long long tmin = -1, tmax = 0;
+    std::map<long long, std::vector<std::pair<long long, long long>>> cu;
+    int nb = 0;
+    double pro = 0, loop = 0, epi = 0;
+    for (size_t b = 0; b < dbg_n / 8; ++b) {
+      const long long* r = &hdb[8 * b];
+      if (!r[0]) continue;
+      ++nb;
+      if (tmin < 0 || r[0] < tmin) tmin = r[0];
+      if (r[3] > tmax) tmax = r[3];
+      pro += r[1] - r[0]; loop += r[2] - r[1]; epi += r[3] - r[2];
+      const long long hw = r[5], key = ((r[6] & 15) << 16) | (hw & 0xFF00);  // xcc | se, sh, cu
+      cu[key].push_back({r[0], r[3]});
+    }
+    int hist[8] = {0};
+    long long worst = 0;
+    for (auto& kv : cu) {
+      hist[std::min<size_t>(kv.second.size(), 7)]++;
+      long long e = 0;
+      for (auto& p : kv.second) e = std::max(e, p.second);
+      worst = std::max(worst, e - tmin);
+    }
+    fprintf(stderr, "  blocks %d on %zu CUs; blocks/CU histogram 1:%d 2:%d 3:%d 4:%d 5+:%d; span %.1f us; avg prologue %.1f loop %.1f epilogue %.1f us\n", nb,
+            cu.size(), hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6] + hist[7], (tmax - tmin) * 0.01, pro / nb * 0.01, loop / nb * 0.01,
+            epi / nb * 0.01);
+    // start-time spread and per-block duration spread
+    long long smax = 0, dmin = 1LL << 60, dmax = 0;
+    for (size_t b = 0; b < dbg_n / 8; ++b) {
+      const long long* r = &hdb[8 * b];
+      if (!r[0]) continue;
+      smax = std::max(smax, r[0] - tmin);
+      dmin = std::min(dmin, r[3] - r[0]);
+      dmax = std::max(dmax, r[3] - r[0]);
+    }
+    fprintf(stderr, "  latest start +%.1f us; block duration min %.1f max %.1f us\n", smax * 0.01, dmin * 0.01, dmax * 0.01);
+    double xd[8] = {0}, xc[8] = {0}; int xn[8] = {0};
+    for (size_t b = 0; b < dbg_n / 8; ++b) {
+      const long long* r = &hdb[8 * b];
+      if (!r[0]) continue;
+      const int x = r[6] & 7;
+      xd[x] += (r[3] - r[0]) * 0.01; xc[x] += (double)r[7] / ((r[3] - r[0]) * 0.01); xn[x]++;
+    }
+    {
+      std::vector<double> du;
+      for (size_t b = 0; b < dbg_n / 8; ++b) if (hdb[8 * b]) du.push_back((hdb[8 * b + 3] - hdb[8 * b]) * 0.01);
+      std::sort(du.begin(), du.end());
+      fprintf(stderr, "  duration percentiles us: p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f max %.0f\n", du[du.size() / 20], du[du.size() / 4], du[du.size() / 2],
+              du[du.size() * 3 / 4], du[du.size() * 19 / 20], du.back());
+      // by original linear block id modulo 64 (8 XCDs x 8): shows placement patterns
+      const int gx = npad / 128;
+      double byd[16] = {0}; int byn[16] = {0};
+      for (size_t b = 0; b < dbg_n / 8; ++b) {
+        if (!hdb[8 * b]) continue;
+        const int cuid = (hdb[8 * b + 5] >> 8) & 15;
+        byd[cuid] += (hdb[8 * b + 3] - hdb[8 * b]) * 0.01; byn[cuid]++;
+      }
+      (void)gx;
+      fprintf(stderr, "  avg by cu_id:");
+      for (int i = 0; i < 16; ++i) if (byn[i]) fprintf(stderr, " %d:%.0f(%d)", i, byd[i] / byn[i], byn[i]);
+      fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "  per XCC avg block us / shader MHz:");
+    for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, " %d:%.0f/%.0f", x, xd[x] / xn[x], xc[x] / xn[x]);
+    fprintf(stderr, "\n");
+    (void)hipFree(dbg);
+  }
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(B); (void)hipFree(so);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;

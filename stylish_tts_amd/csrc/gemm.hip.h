@@ -53,6 +53,7 @@ struct GemmArgs {
   const int* seg_off;  // device [n_utt + 1], rows
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
+  long long* dbg;         // block-timeline records (only written when built with -DSTTS_GEMM_TRACE; tools/gemm_bench.py)
   const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
   int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
   float* partial;         // [ksplit][rows_total][ld_part] raw partial sums (EPI_STORE only; splitk_reduce_kernel finishes)
@@ -127,6 +128,18 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   if (row0 >= hi) return;
   const int m0 = bx * BM;
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef STTS_GEMM_TRACE
+  // per-block record [t_start, t_prologue_end, t_loop_end, t_end (10 ns ticks), iterations, HW_ID, XCC_ID, shader cycles]
+  const unsigned dbg_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  auto stamp = [&](int i) { if (a.dbg && tid == 0) a.dbg[8 * (long)dbg_blk + i] = wall_clock64(); };
+  const long long dbg_c0 = clock64();
+  if (a.dbg && tid == 0) { a.dbg[8 * (long)dbg_blk + 5] = __builtin_amdgcn_s_getreg(0xF804); a.dbg[8 * (long)dbg_blk + 6] = __builtin_amdgcn_s_getreg(0xF814); }
+  auto stamp_end = [&]() { stamp(3); if (a.dbg && tid == 0) a.dbg[8 * (long)dbg_blk + 7] = clock64() - dbg_c0; };
+#else
+  auto stamp = [&](int) {};
+  auto stamp_end = [&]() {};
+#endif
+  stamp(0);
   const int kg = (tid >> 6) / (WARPS_M * WARPS_N), wid = (tid >> 6) % (WARPS_M * WARPS_N);  // K-group, wave position
   const int wn = wid / WARPS_M, wm = wid % WARPS_M;
   (void)kg;
@@ -337,6 +350,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   gload(rsB);  // tile 1
   gload(rsA);  // tile 2   (the cursor clamps at the last tile, extra fetches are harmless re-loads)
   __syncthreads();
+  stamp(1);
 
   // iteration `it` computes tile it from buffer it&1; tile it+1 (fetched during iteration it-2) moves registers -> the
   // other buffer (legal: that buffer was last read in iteration it-1 and a barrier has passed); then tile it+3 is fetched
@@ -365,6 +379,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     iter(it, rsB);
     if (it + 1 < total) iter(it + 1, rsA);
   }
+  stamp(2);
+#ifdef STTS_GEMM_TRACE
+  if (a.dbg && tid == 0) a.dbg[8 * (long)dbg_blk + 4] = total;
+#endif
   }
 
   if constexpr (KSPLIT == 2) {
@@ -406,6 +424,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
             if (rl < nvalid) P[(long)(row0 + rl) * a.ld_part + n] = acc[i][j][r];
           }
       }
+      stamp_end();
       return;
     }
 #pragma unroll
@@ -501,6 +520,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       }
     }
   }
+  stamp_end();
 }
 
 // Finishes a block-level split-K contraction: Y = (act(sum_ks partial[ks] + bias) [+ R]) * alpha, partials summed in a
