@@ -20,6 +20,7 @@
 // Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
 // epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
 #pragma once
+#include <cmath>
 #include <algorithm>
 #include <vector>
 
@@ -633,7 +634,22 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   const long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
   int tile = force_tile;
   const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
-  if (tile == 0) tile = blocks128 >= 200 ? (paired ? 2 : 5) : (blocks128 >= 24 ? (paired ? 2 : 6) : 3);
+  if (tile == 0) {
+    if (blocks128 < 24) tile = 3;
+    else if (paired) tile = 2;
+    else {
+      // 128x128 vs 128x64 by whole-chip rounds: a CU's matrix pipes are the shared resource, so the launch takes about
+      // ceil(blocks / 256 CUs) block-times however many blocks are co-resident.  288 blocks of 128x128 (a 3.5 s batch
+      // of 8) cost two rounds; 576 of 128x64 cost three half-sized ones.  (Block-timeline trace, profiles/.)
+      const int mt = npad / 128;
+      const bool uniform = (long)max_rows * n_utt == a.rows_total;
+      auto rounds_cost = [&](int bn, double penalty) {
+        const double nb = uniform ? (double)mt * n_utt * ceil_div(max_rows, bn) : mt * ((double)a.rows_total / bn + 0.5 * n_utt);
+        return std::ceil(nb / 256.0) * bn * penalty;
+      };
+      tile = rounds_cost(128, 1.0) <= rounds_cost(64, 1.03) ? 5 : 6;
+    }
+  }
   // (intra-block K-split, tiles 8-10, and 2-wave tiles measured no better than these at any layer shape: every
   //  configuration plateaus at ~80 % matrix-pipe occupancy)
   // Block-level split-K for launches that cannot fill the chip (phoneme-rate layers, B = 1): one wave's MFMA chain over
