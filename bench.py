@@ -197,7 +197,7 @@ def main():
             except Exception:
                 traffic = None
         out["roofline"] = {
-            "kernel": "conv_gemm_f32 (all Conv1d/Linear contractions of the step)",
+            "kernel": "conv_gemm_f32 + wn_layer_kernel (all Conv1d/Linear contractions of the step)",
             "bound": "mfma",
             "achieved": round(achieved, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS,

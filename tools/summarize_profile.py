@@ -3,7 +3,7 @@ contraction kernels' average launch duration to set beside bench.py's HIP-event 
 import csv, glob, json, sys
 
 src, out_prefix, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-f = glob.glob(src + "/*/*kernel_stats.csv")[0]
+f = glob.glob(src + "/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 lines = ["| kernel | launches/step | ms/step | avg us | share |", "|---|---|---|---|---|"]
