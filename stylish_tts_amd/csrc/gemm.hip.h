@@ -20,6 +20,7 @@
 // Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
 // epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
 #pragma once
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <algorithm>
 #include <vector>
@@ -605,17 +606,25 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
   return 2.0 * (double)a.rows_total * (double)a.wrows * k;
 }
 
+// With a profiler event pair the kernel is launched through hipExtLaunchKernelGGL, whose events take the dispatch's own
+// begin / end timestamps (what rocprofv3 reports), instead of bracketing the launch with stream markers.
+#define STTS_LAUNCH_TIMED(kernel, grid, block, st, e0, e1, ...)                                   \
+  do {                                                                                            \
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, __VA_ARGS__);            \
+    else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                             \
+  } while (0)
+
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false>
-inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows) {
+inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL>), grid, block, 0, st, a); break;
-    case EPI_SPLIT_ACC: hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL>), grid, block, 0, st, a); break;
+    case EPI_STORE: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL>), grid, block, st, e0, e1, a); break;
+    case EPI_SPLIT_ACC: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL>), grid, block, st, e0, e1, a); break;
     default:
       if constexpr (BM / WM >= 64) {
-        if (epi == EPI_GATE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS, GL>), grid, block, 0, st, a);
-        else if (epi == EPI_COUPLE) hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS, GL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, GL>), grid, block, 0, st, a);
+        if (epi == EPI_GATE) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS, GL>), grid, block, st, e0, e1, a);
+        else if (epi == EPI_COUPLE) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS, GL>), grid, block, st, e0, e1, a);
+        else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, GL>), grid, block, st, e0, e1, a);
       }
       break;
   }
@@ -672,25 +681,26 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     }
   }
   GemmProfiler& prof = gemm_profiler();
-  if (prof.on) (void)hipEventRecord(prof.next(), st);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof.on) {
+    e0 = prof.next();
+    e1 = prof.next();
+  }
   switch (tile) {
-    case 2: launch_cfg<128, 64, 2, 2>(st, as, epi, npad, n_utt, max_rows); break;
-    case 5: launch_cfg<128, 128, 4, 2>(st, as, epi, npad, n_utt, max_rows); break;    // 8 waves per block
-    case 6: launch_cfg<128, 64, 4, 2>(st, as, epi, npad, n_utt, max_rows); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
-    case 11: launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows); break;  // LDS-DMA staging, 8 waves
-    case 13: launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows); break;   // LDS-DMA staging, 64-row tile
-    case 8: launch_cfg<128, 128, 4, 2, 2>(st, as, epi, npad, n_utt, max_rows); break;  // 16 waves: 8 positions x 2 K-groups
-    default: launch_cfg<128, 32, 2, 1>(st, as, epi, npad, n_utt, max_rows); break;
+    case 2: launch_cfg<128, 64, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 5: launch_cfg<128, 128, 4, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;    // 8 waves per block
+    case 6: launch_cfg<128, 64, 4, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
+    case 11: launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // LDS-DMA staging, 8 waves
+    case 13: launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // LDS-DMA staging, 64-row tile
+    case 8: launch_cfg<128, 128, 4, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
+    default: launch_cfg<128, 32, 2, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
   }
   if (as.ksplit > 1) {
     const long work = (long)a.rows_total * ((a.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), 0, st, as.partial, as.ksplit,
                        a.rows_total, as.ld_part, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha, a.Y, a.ldy, a.ycol0);
   }
-  if (prof.on) {
-    (void)hipEventRecord(prof.next(), st);
-    prof.flops.push_back(gemm_algorithmic_flops(a));
-  }
+  if (prof.on) prof.flops.push_back(gemm_algorithmic_flops(a));
   STTS_HIP(hipGetLastError());
   return 0;
 }

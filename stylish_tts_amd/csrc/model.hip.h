@@ -635,12 +635,13 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         }
       }
       GemmProfiler& prof = gemm_profiler();
-      if (prof.on) (void)hipEventRecord(prof.next(), st);
-      hipLaunchKernelGGL(wn_layer_kernel<4>, dim3(ceil_div(ml, 32), s.n_utt), dim3(1024), 0, st, w);
+      hipEvent_t e0 = nullptr, e1 = nullptr;
       if (prof.on) {
-        (void)hipEventRecord(prof.next(), st);
+        e0 = prof.next();
+        e1 = prof.next();
         prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh) + extra);
       }
+      STTS_LAUNCH_TIMED(wn_layer_kernel<4>, dim3(ceil_div(ml, 32), s.n_utt), dim3(1024), st, e0, e1, w);
       std::swap(hcur, hnext);
     }
     STTS_HIP(hipGetLastError());
