@@ -20,6 +20,8 @@
 // Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
 // epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
 #pragma once
+#include <mutex>
+#include <map>
 #include <hip/hip_ext.h>
 #include <cmath>
 #include <algorithm>
@@ -546,22 +548,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
-// grow-only scratch for split-K partial sums (one per process = per GPU)
-inline float* splitk_scratch(size_t bytes) {
-  static float* buf = nullptr;
-  static size_t cap = 0;
-  if (bytes > cap) {
-    if (buf) {
+// grow-only scratch for split-K partial sums, one buffer per launch stream (contractions issued on different streams
+// may run concurrently and must not share partials)
+inline float* splitk_scratch(hipStream_t st, size_t bytes) {
+  struct Buf {
+    float* p = nullptr;
+    size_t cap = 0;
+  };
+  static std::map<hipStream_t, Buf> bufs;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  Buf& b = bufs[st];
+  if (bytes > b.cap) {
+    if (b.p) {
       (void)hipDeviceSynchronize();
-      (void)hipFree(buf);
+      (void)hipFree(b.p);
     }
-    cap = bytes + bytes / 2;
-    if (hipMalloc(&buf, cap) != hipSuccess) {
-      buf = nullptr;
-      cap = 0;
+    b.cap = bytes + bytes / 2;
+    if (hipMalloc(&b.p, b.cap) != hipSuccess) {
+      b.p = nullptr;
+      b.cap = 0;
     }
   }
-  return buf;
+  return b.p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,7 +681,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
     int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, 512 / std::max<long>(blocks, 1)));
     if (ksp >= 2) {
-      float* part = splitk_scratch((size_t)ksp * a.rows_total * npad * sizeof(float));
+      float* part = splitk_scratch(st, (size_t)ksp * a.rows_total * npad * sizeof(float));
       if (part) {
         as.ksplit = ksp;
         as.partial = part;

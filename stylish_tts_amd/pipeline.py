@@ -24,6 +24,9 @@ class Synthesizer:
         self.eng = engine
         self.cfg = engine.cfg
         self.text_cleaner = TextCleaner(self.cfg.symbol) if "symbol" in self.cfg else None
+        # the three text encoders only share the tokens: two of them (with their style encoders) run on side streams
+        # next to the duration predictor and the host read of the frame counts
+        self._side = [torch.cuda.Stream(device=engine.device) for _ in range(2)]
 
     def infer(self, texts: Sequence[str], noise: Optional[Dict[str, torch.Tensor]] = None, out_prefix: Optional[str] = None, combine: bool = False):
         """Phoneme strings → int16 waveforms, all utterances in one pass (the loop body of ``train/test_onnx.py:48-90``).
@@ -48,6 +51,20 @@ class Synthesizer:
         L = [len(t) for t in token_lists]
         toks = torch.tensor([int(v) for t in token_lists for v in t], dtype=torch.int64, device=dev)
         sp = Segments(L, dev)
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        # 2a/3a. the pitch/energy and speech text + style encoders: phoneme-rate, independent of the durations
+        side_out = []
+        for which, stream in ((2, self._side[0]), (1, self._side[1])):
+            with torch.cuda.stream(stream):
+                stream.wait_event(ready)
+                e = eng.text_encoder(which, sp, toks)
+                y = eng.text_style(which, sp, e)
+                for t in (e, y):
+                    t.record_stream(main)  # consumed on the caller's stream below
+                side_out.append((e, y))
+        (pe_enc, pe_style), (enc, style) = side_out
         # 1. durations (DurationPredictor + DurationProcessor.prediction_to_duration)
         _, dur = eng.duration(sp, toks)
         csum = torch.cumsum(dur, 0)
@@ -56,13 +73,11 @@ class Synthesizer:
         T = [int(v) for v in T]
         st = Segments(T, dev)
         st4 = st.scaled(4)
-        # 2. pitch / energy (pe_text_encoder -> pe_text_style_encoder -> PitchEnergyPredictor)
-        pe_enc = eng.text_encoder(2, sp, toks)
-        pe_style = eng.text_style(2, sp, pe_enc)
+        main.wait_stream(self._side[0])
+        main.wait_stream(self._side[1])
+        # 2b. pitch / energy (PitchEnergyPredictor on the pe encoders' outputs)
         f0, en = eng.pitch_energy(sp, st, dur, pe_enc, pe_style)
-        # 3. speech predictor front (text_encoder, style_encoder, length regulator, x4 upsampling)
-        enc = eng.text_encoder(1, sp, toks)
-        style = eng.text_style(1, sp, enc)
+        # 3b. speech predictor front (length regulator, x4 upsampling)
         asr = eng.length_regulate(sp, st4, dur, 4, enc, self.cfg.inter_dim)
         p4, e4 = eng.upsample4(st, st4, f0), eng.upsample4(st, st4, en)
         # 4. frame path

@@ -188,10 +188,15 @@ class HipModel:
 
     # ------------------------------------------------------------------ phoneme-rate stages (packed tokens)
     def _ph_ws(self, n_tok: int, n_frames: int, n_utt: int) -> torch.Tensor:
+        """Grow-only phoneme-stage workspace, one per launch stream (stages on different streams may run concurrently)."""
         need = int(self.lib.stts_phoneme_workspace_bytes(self.ctx, n_tok, n_frames, n_utt))
-        if getattr(self, "_pws", None) is None or self._pws.numel() < need:
-            self._pws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._pws
+        if not hasattr(self, "_pws"):
+            self._pws = {}
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._pws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._pws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def text_encoder(self, which: int, seg: Segments, tokens: torch.Tensor, return_hidden=False):
         """tokens int64 [n_tok] (packed) -> mu [n_tok, inter] (+ last hidden [n_tok, 128])."""
