@@ -666,6 +666,10 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
         return std::ceil(nb / 256.0) * bn * penalty;
       };
       tile = rounds_cost(128, 1.0) <= rounds_cost(64, 1.03) ? 5 : 6;
+      // one 128x128 tile per CU (B = 8: every 512-channel layer): two K-groups of 8 waves share each staged tile, which
+      // keeps the matrix pipes busier than 8 waves do (118 vs 125.5 us) and beats cutting K over two blocks plus the
+      // reduce pass (131 us)
+      if (tile == 5 && blocks128 <= 256) tile = 8;
     }
   }
   // (intra-block K-split, tiles 8-10, and 2-wave tiles measured no better than these at any layer shape: every
@@ -674,7 +678,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
   GemmArgs as = a;
   as.ksplit = 1;
-  if (force_tile == 0 && epi == EPI_STORE && !a.sumsq_part) {
+  if (force_tile == 0 && epi == EPI_STORE && !a.sumsq_part && tile != 8) {
     const int bn = tile == 5 ? 128 : (tile == 3 ? 32 : 64);
     const long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
     int iters = 0;
