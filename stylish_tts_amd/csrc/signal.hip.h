@@ -115,34 +115,59 @@ __global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0,
 }
 
 // ---------------------------------------------------------------------------------------------
-// N-point complex FFT in LDS (Stockham autosort, radix 2), 256 threads.  tw[m * tw_scale] = exp(-2*pi*i*m/N)
+// N-point complex FFT in LDS (Stockham autosort, radix 4), 256 threads.  tw[m * tw_scale] = exp(-2*pi*i*m/N)
 // for m < N/2 (forward); the inverse conjugates on the fly.  Input in `a`; returns the buffer holding the result.
 // ---------------------------------------------------------------------------------------------
 template <typename T2, int N, bool INVERSE>
 __device__ __forceinline__ T2* fft_lds(T2* a, T2* b, const T2* tw, int tw_scale) {
-  const int tid = threadIdx.x;
+  // radix-4 Stockham autosort: N = 4^5 = 1024 points, one butterfly per thread per stage, 5 stages / 5 barriers
+  static_assert(N == 1024, "fft_lds: 256 threads x radix 4 x 5 stages");
+  using T = decltype(T2().x);
+  const int j = threadIdx.x;  // 0 .. N/4-1
   T2* in = a;
   T2* out = b;
-#pragma unroll 1
-  for (int Ns = 1; Ns < N; Ns <<= 1) {
-    const int tstride = (N / 2) / Ns * tw_scale;
-#pragma unroll
-    for (int q = 0; q < N / 512; ++q) {
-      const int j = tid + q * 256;  // 0 .. N/2-1
-      const int k = j & (Ns - 1);
-      T2 w = tw[k * tstride];
-      if (INVERSE) w.y = -w.y;
-      const T2 x0 = in[j], x1 = in[j + N / 2];
-      T2 t;
-      t.x = x1.x * w.x - x1.y * w.y;
-      t.y = x1.x * w.y + x1.y * w.x;
-      const int j0 = ((j - k) << 1) + k;
-      T2 o0, o1;
-      o0.x = x0.x + t.x; o0.y = x0.y + t.y;
-      o1.x = x0.x - t.x; o1.y = x0.y - t.y;
-      out[j0] = o0;
-      out[j0 + Ns] = o1;
+  auto cmul = [](const T2 x, const T2 w) {
+    T2 r;
+    r.x = x.x * w.x - x.y * w.y;
+    r.y = x.x * w.y + x.y * w.x;
+    return r;
+  };
+  auto twid = [&](int idx) {  // exp(-+ 2 pi i idx / N); the table covers half a turn (idx * tw_scale < table length)
+    const int half = N / 2;
+    T2 w = tw[(idx >= half ? idx - half : idx) * tw_scale];
+    if (idx >= half) {
+      w.x = -w.x;
+      w.y = -w.y;
     }
+    if (INVERSE) w.y = -w.y;
+    return w;
+  };
+#pragma unroll 1
+  for (int Ns = 1; Ns < N; Ns <<= 2) {
+    const int k = j & (Ns - 1);
+    const int base = k * (N / (4 * Ns));  // angle unit 2 pi / N
+    T2 v0 = in[j], v1 = in[j + N / 4], v2 = in[j + N / 2], v3 = in[j + 3 * N / 4];
+    if (Ns > 1) {
+      v1 = cmul(v1, twid(base));
+      v2 = cmul(v2, twid(2 * base));
+      v3 = cmul(v3, twid(3 * base));
+    }
+    T2 a0, a1, a2, a3;
+    a0.x = v0.x + v2.x; a0.y = v0.y + v2.y;
+    a1.x = v0.x - v2.x; a1.y = v0.y - v2.y;
+    a2.x = v1.x + v3.x; a2.y = v1.y + v3.y;
+    const T dx = v1.x - v3.x, dy = v1.y - v3.y;
+    if (INVERSE) {  // (v1 - v3) * (+i)
+      a3.x = -dy; a3.y = dx;
+    } else {        // (v1 - v3) * (-i)
+      a3.x = dy; a3.y = -dx;
+    }
+    const int j0 = ((j - k) << 2) + k;
+    T2 o;
+    o.x = a0.x + a2.x; o.y = a0.y + a2.y; out[j0] = o;
+    o.x = a1.x + a3.x; o.y = a1.y + a3.y; out[j0 + Ns] = o;
+    o.x = a0.x - a2.x; o.y = a0.y - a2.y; out[j0 + 2 * Ns] = o;
+    o.x = a1.x - a3.x; o.y = a1.y - a3.y; out[j0 + 3 * Ns] = o;
     __syncthreads();
     T2* tmp = in;
     in = out;
