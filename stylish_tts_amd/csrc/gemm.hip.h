@@ -602,11 +602,13 @@ inline GemmProfiler& gemm_profiler() {
   return p;
 }
 inline const float* zero_page() {
-  static float* z = nullptr;
-  if (!z) {
-    (void)hipMalloc(&z, 256);
-    (void)hipMemset(z, 0, 256);
-  }
+  static float* z = [] {  // initialised once, also under concurrent first calls from several host threads
+    float* p = nullptr;
+    (void)hipMalloc(&p, 256);
+    (void)hipMemset(p, 0, 256);
+    (void)hipDeviceSynchronize();
+    return p;
+  }();
   return z;
 }
 inline double gemm_algorithmic_flops(const GemmArgs& a) {

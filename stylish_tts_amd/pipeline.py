@@ -8,6 +8,7 @@ sequences (per-utterance semantics, no padding), with a single host read in the 
 """
 from __future__ import annotations
 
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -27,6 +28,9 @@ class Synthesizer:
         # the three text encoders only share the tokens: two of them (with their style encoders) run on side streams
         # next to the duration predictor and the host read of the frame counts
         self._side = [torch.cuda.Stream(device=engine.device) for _ in range(2)]
+        # ... each issued from its own host thread: a text encoder is ~120 launches (~0.5 ms of host time), so one
+        # thread cannot feed three streams (the C calls release the GIL)
+        self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="stts-side")
 
     def infer(self, texts: Sequence[str], noise: Optional[Dict[str, torch.Tensor]] = None, out_prefix: Optional[str] = None, combine: bool = False):
         """Phoneme strings → int16 waveforms, all utterances in one pass (the loop body of ``train/test_onnx.py:48-90``).
@@ -55,16 +59,17 @@ class Synthesizer:
         ready = torch.cuda.Event()
         ready.record(main)
         # 2a/3a. the pitch/energy and speech text + style encoders: phoneme-rate, independent of the durations
-        side_out = []
-        for which, stream in ((2, self._side[0]), (1, self._side[1])):
+        def encode(which, stream):
+            torch.cuda.set_device(dev)
             with torch.cuda.stream(stream):
                 stream.wait_event(ready)
                 e = eng.text_encoder(which, sp, toks)
                 y = eng.text_style(which, sp, e)
                 for t in (e, y):
                     t.record_stream(main)  # consumed on the caller's stream below
-                side_out.append((e, y))
-        (pe_enc, pe_style), (enc, style) = side_out
+            return e, y
+
+        jobs = [self._pool.submit(encode, 2, self._side[0]), self._pool.submit(encode, 1, self._side[1])]
         # 1. durations (DurationPredictor + DurationProcessor.prediction_to_duration)
         _, dur = eng.duration(sp, toks)
         csum = torch.cumsum(dur, 0)
@@ -73,6 +78,7 @@ class Synthesizer:
         T = [int(v) for v in T]
         st = Segments(T, dev)
         st4 = st.scaled(4)
+        (pe_enc, pe_style), (enc, style) = jobs[0].result(), jobs[1].result()
         main.wait_stream(self._side[0])
         main.wait_stream(self._side[1])
         # 2b. pitch / energy (PitchEnergyPredictor on the pe encoders' outputs)
