@@ -152,12 +152,16 @@ int stts_length_regulate(stts_ctx* ctx, void* stream, int n_utt, const int32_t* 
 int stts_upsample4(stts_ctx* ctx, void* stream, int n_utt, const int32_t* off_T_host, const int32_t* off_T, const int32_t* off_T4,
                    const float* x, float* y);
 
+/* One explicit-Euler update of the flow-matching sampler, x += dt * v over n floats
+ * (models/cfm/cfm.py:65-84, CfmSampler.solve_euler: `x = x + dt * dphi_dt`). */
+int stts_euler_step(void* stream, float* x, const float* v, float dt, int64_t n);
+
 /* Layout bridge for the nn.Module shims: reference [B, C, T] (equal T) <-> time-major rows. */
 int stts_to_time_major(void* stream, const float* x_bct, int B, int C, int T, float* y, int ldy);
 int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, int T, float* y_bct);
 
-/* Measurement hook (bench.py roofline leg): between begin and end every conv_gemm_f32 launch is bracketed by
- * HIP events on its own stream.  end() synchronises and returns the launch count, the summed kernel time and
+/* Measurement hook (bench.py roofline leg): between begin and end every conv_gemm_f32 / wn_layer_kernel launch carries a
+ * HIP start/stop event pair on its own stream.  end() synchronises and returns the launch count, the summed kernel time and
  * the summed ALGORITHMIC flops (2 * rows * cout * cin * taps, un-padded sizes). */
 int stts_profile_begin(void);
 int stts_profile_end(void* stream, int* launches, double* total_ms, double* total_flops);

@@ -629,3 +629,23 @@ def export_model_forward(texts, lengths, alignment, noise, weights: Dict[str, W]
         texts, lengths, alignment, pitch, energy, noise, weights["speech_predictor"], cfg, branch_hint
     )
     return audio, pitch, energy
+
+
+def cfm_solve_euler(z, n_timesteps, estimator, temperature=1.0):
+    """CfmSampler.forward + solve_euler (models/cfm/cfm.py:44-84) in fp32: the time grid is torch.linspace(0, 1, n + 1)
+    (``start + i * step`` below the midpoint, ``end - (n - i) * step`` above it, all in fp32) and the running time /
+    step size are updated as ``t += dt ; dt = t_span[step + 1] - t``.  ``estimator(x, t)`` returns dphi/dt."""
+    n = int(n_timesteps)
+    step = F32(1.0) / F32(n)
+    idx = np.arange(n + 1)
+    t_span = np.where(idx < (n + 1) // 2, F32(0.0) + idx.astype(F32) * step, F32(1.0) - (n - idx).astype(F32) * step).astype(F32)
+    x = (z.astype(F32) * F32(temperature)).astype(F32)
+    t = t_span[0]
+    dt = F32(t_span[1] - t_span[0])
+    for k in range(1, n + 1):
+        v = estimator(x, np.full((x.shape[0],), t, F32)).astype(F32)
+        x = (x + (dt * v).astype(F32)).astype(F32)
+        t = F32(t + dt)
+        if k < n:
+            dt = F32(t_span[k + 1] - t)
+    return x

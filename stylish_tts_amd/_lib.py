@@ -68,6 +68,7 @@ SIGNATURES = {
     "stts_duration_to_alignment": (_I, [_P, _P, _I, _I, _P]),
     "stts_length_regulate": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I, _P, _I, _I, _P, _I, _P]),
     "stts_upsample4": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    "stts_euler_step": (_I, [_P, _P, _P, C.c_float, C.c_int64]),
     "stts_to_time_major": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "stts_to_channel_major": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stts_profile_begin": (_I, []),

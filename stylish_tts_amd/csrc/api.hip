@@ -184,6 +184,15 @@ int stts_upsample4(stts_ctx* c, void* stream, int n_utt, const int32_t* off_T_ho
   API_END
 }
 
+int stts_euler_step(void* stream, float* x, const float* v, float dt, int64_t n) {
+  API_BEGIN
+  STTS_CHECK(x && v && n >= 0, "bad argument");
+  if (n) hipLaunchKernelGGL(euler_step_kernel, dim3((unsigned)std::min<int64_t>(4096, (n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x, v, dt, (long)n);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
 int stts_to_time_major(void* stream, const float* x, int B, int C, int T, float* y, int ldy) {
   API_BEGIN
   STTS_CHECK(ldy >= C, "ldy < C");

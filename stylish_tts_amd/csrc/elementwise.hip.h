@@ -489,4 +489,14 @@ __global__ void fill_kernel(float* p, long n, float v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// x += dt * v (CfmSampler.solve_euler, models/cfm/cfm.py:79); separate multiply and add like the reference's
+// `x + dt * dphi_dt` (no fused multiply-add, so the result is bit-identical to torch's two roundings)
+__global__ void __launch_bounds__(256) euler_step_kernel(float* __restrict__ x, const float* __restrict__ v, float dt, long n) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float p = dt * v[i];
+    x[i] = x[i] + p;
+  }
+}
+
 }  // namespace stts

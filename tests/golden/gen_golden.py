@@ -424,9 +424,28 @@ def text_golden():
     print("  wrote text_tokens.json", os.path.getsize(path))
 
 
+def cfm_golden():
+    """CfmSampler.forward (models/cfm/cfm.py:44-84) with a closed-form estimator: pins the time grid and update order."""
+    from stylish_tts.train.models.cfm.cfm import CfmSampler
+
+    def estimator(x, t, mask, cond, gain):
+        return (cond - x) * (0.5 + t.reshape(-1, 1, 1)) * gain + torch.sin(3.0 * x)
+
+    out = {}
+    for n in (1, 4, 7, 32):
+        z = t(synth.normal(f"cfm.z{n}", (2, 80, 37)))
+        cond = t(synth.normal(f"cfm.c{n}", (2, 80, 37)))
+        y = CfmSampler(estimator)(z, None, n, temperature=0.8, cond=cond, gain=1.7)
+        out[f"z{n}"], out[f"cond{n}"], out[f"y{n}"] = z, cond, y
+    save("cfm_euler", **out)
+
+
 if __name__ == "__main__":
-    if "--only-text" in sys.argv:
+    if "--only-cfm" in sys.argv:
+        cfm_golden()
+    elif "--only-text" in sys.argv:
         _ = text_golden()
     else:
         main()
         text_golden()
+        cfm_golden()
