@@ -32,6 +32,7 @@ import torch  # noqa: E402
 BATCH, T_MEL, SR = 8, 240, 24000
 T4 = 4 * T_MEL
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_PEAK_TFLOPS = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": 2500.0, "f16": 2500.0}  # dense 16-bit MFMA (same guide)
 
 
 def synth_inputs(rank: int, device):
@@ -60,6 +61,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step (BASELINE cfg2 = 8; other values are side experiments)")
     ap.add_argument("--mel-frames", type=int, default=240, help="mel frames per utterance (cfg2 = 240 = 3.0 s)")
+    ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
+                    help="operand precision of the contractions; f32 = BASELINE cfg2 (the bench line), bf16 / f16 = cfg3 / cfg5 arithmetic (side experiments)")
     ap.add_argument("--cpu-utts", type=int, default=4, help="utterances the CPU baseline times (bounded sample)")
     args = ap.parse_args()
     global BATCH, T_MEL, T4
@@ -97,7 +100,7 @@ def main():
     sd = params.synth_state_dict(spec, 0, prefix="speech_predictor.") if rank == 0 else None
     if world > 1:
         sd = broadcast_state_dict(sd, spec, device, src=0)  # RCCL broadcast of the weights, once
-    model = HipModel(cfg, local)
+    model = HipModel(cfg, local, precision=args.precision)
     model.load_weights({"speech_predictor": sd}, which=7)
 
     seg = Segments([T4] * BATCH, device)
@@ -165,10 +168,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.precision,
         "data": "synthetic",
         "config": {
-            "workload": ("cfg2: " if (BATCH, T_MEL) == (8, 240) else "side experiment: ") + f"LJSpeech-shaped batch={BATCH} x {T_MEL / 80:.1f} s (T={T_MEL} mel frames, {T4 * 75} samples @24 kHz) fp32, "
+            "workload": ("cfg2: " if (BATCH, T_MEL, args.precision) == (8, 240, "f32") else "side experiment: ") + f"LJSpeech-shaped batch={BATCH} x {T_MEL / 80:.1f} s (T={T_MEL} mel frames, {T4 * 75} samples @24 kHz) " + ("fp32" if args.precision == "f32" else f"{args.precision} matrix-core operands, fp32 accumulate") + ", "
                         "Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); no diffusion step exists in the reference",
             "batch_per_gpu": BATCH,
             "global_batch": BATCH * world,
@@ -200,9 +203,9 @@ def main():
             "kernel": "conv_gemm_f32 + wn_layer_kernel (all Conv1d/Linear contractions of the step)",
             "bound": "mfma",
             "achieved": round(achieved, 2),
-            "peak": FP32_MFMA_PEAK_TFLOPS,
+            "peak": MFMA_PEAK_TFLOPS[args.precision],
             "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "frac": round(achieved / MFMA_PEAK_TFLOPS[args.precision], 4),
             "traffic": traffic,
             "launches_per_step": launches,
             "avg_launch_ms": round(avg_ms, 5),

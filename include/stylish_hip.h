@@ -65,6 +65,12 @@ enum {
   STTS_W_ALL = 255
 };
 int stts_finalize_weights(stts_ctx* ctx, int which);
+/* Operand precision of the Conv1d / Linear contractions (call before the first stts_finalize_weights).
+ * F32 is the reference's arithmetic (BASELINE cfg2).  BF16 / F16: activations stay fp32 in HBM and are rounded
+ * to nearest-even when a tile is staged for the matrix cores, weights are stored pre-rounded, products
+ * accumulate in fp32 (BASELINE cfg3 / cfg5); norms, gates, FFTs and every non-contraction kernel stay fp32. */
+enum { STTS_PREC_F32 = 0, STTS_PREC_BF16 = 1, STTS_PREC_F16 = 2 };
+int stts_set_precision(stts_ctx* ctx, int precision);
 /* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz
  * (the reference raises there, models/generator.py:285).  Synchronises the stream. */
 int stts_check_status(stts_ctx* ctx, void* stream);
@@ -169,7 +175,7 @@ int stts_profile_end(void* stream, int* launches, double* total_ms, double* tota
 /* Single operators, exposed for parity tests (same kernels the stages use). */
 /* F.conv1d(stride 1, zero pad (k-1)/2*dil) on time-major rows; w is the reference layout [cout, cin, k] on the HOST. */
 int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,
-                   const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile);
+                   const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile, int precision);
 /* AdaptiveDecoderBlock.forward (models/ada_norm.py:166-182) with weights named `prefix` + reference keys. */
 int stts_op_adain_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host,
                         const int32_t* seg_off_dev, const float* x, int ldx, int cin, int cout, const float* style, float* y, int ldy,

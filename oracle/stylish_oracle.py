@@ -54,10 +54,31 @@ def wn_legacy(w: W, p: str) -> np.ndarray:
     return weight_norm(w[p + ".weight_g"], w[p + ".weight_v"])
 
 
+# Operand rounding of the 16-bit modes (include/stylish_hip.h:stts_set_precision): None = the reference's fp32 arithmetic;
+# "bf16" / "f16" = both operands of every contraction the HIP path runs on the matrix cores (Conv1d with more than one
+# input and output channel, Linear except the style projections) are rounded to nearest-even first, products and sums
+# stay fp32.  Used by the 16-bit parity tests only; the goldens pin the fp32 behaviour.
+OPERAND_ROUND = None
+
+
+def round_operand(a):
+    if OPERAND_ROUND is None:
+        return a
+    a = np.ascontiguousarray(a, F32)
+    if OPERAND_ROUND == "f16":
+        return a.astype(np.float16).astype(F32)
+    assert OPERAND_ROUND == "bf16", OPERAND_ROUND
+    u = a.view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(F32).reshape(a.shape)
+
+
 def conv1d(x, wt, b=None, padding=0, dilation=1, groups=1):
     """F.conv1d, stride 1.  x [B,Cin,T], wt [Cout,Cin/groups,K]."""
     B, Cin, T = x.shape
     Cout, Cg, K = wt.shape
+    if groups == 1 and Cin > 1 and Cout > 1:
+        x, wt = round_operand(x), round_operand(wt)
     xp = np.pad(x, ((0, 0), (0, 0), (padding, padding))) if padding else x
     Tout = T + 2 * padding - dilation * (K - 1)
     y = np.zeros((B, Cout, Tout), F32)
@@ -76,7 +97,10 @@ def conv1d(x, wt, b=None, padding=0, dilation=1, groups=1):
     return y.astype(F32)
 
 
-def linear(x, wt, b=None):
+def linear(x, wt, b=None, exact=False):
+    """exact: a projection the HIP path evaluates in fp32 outside the matrix cores (style fc, WN cond_layer)."""
+    if not exact:
+        x, wt = round_operand(x), round_operand(wt)
     y = np.matmul(x, wt.T)
     if b is not None:
         y = y + b
@@ -127,7 +151,7 @@ def sequence_mask(lengths, max_len):
 # --------------------------------------------------------------------------------------
 def adaptive_instance(x, s, w: W, p: str):
     """AdaptiveInstance.forward (models/ada_norm.py:135-139)."""
-    h = linear(s, w[p + ".fc.weight"], w[p + ".fc.bias"])
+    h = linear(s, w[p + ".fc.weight"], w[p + ".fc.bias"], exact=True)
     C = x.shape[1]
     gamma, beta = h[:, :C, None], h[:, C:, None]
     return ((1 + gamma) * instance_norm(x) + beta).astype(F32)
@@ -135,7 +159,7 @@ def adaptive_instance(x, s, w: W, p: str):
 
 def adaptive_layer_norm(x_btc, s, w: W, p: str, eps=1e-5):
     """AdaptiveLayerNorm.forward on [B,T,C] (models/ada_norm.py:193-201)."""
-    h = linear(s, w[p + ".fc.weight"], w[p + ".fc.bias"])
+    h = linear(s, w[p + ".fc.weight"], w[p + ".fc.bias"], exact=True)
     C = x_btc.shape[-1]
     gamma, beta = h[:, None, :C], h[:, None, C:]
     return ((1 + gamma) * layer_norm_last(x_btc, eps) + beta).astype(F32)
@@ -200,7 +224,7 @@ def prior_encoder(x, noise, w: W, p: str = "prior_encoder."):
 def wn_forward(x, g, w: W, p: str, hidden=128, n_layers=4, k=5):
     """WN.forward (models/flow.py:63-88); x_mask is the scalar 1 on the inference path."""
     output = np.zeros_like(x)
-    gc = linear(g.transpose(0, 2, 1), wn_legacy(w, p + "cond_layer"), w[p + "cond_layer.bias"]).transpose(0, 2, 1)  # [B, 2H*L, 1]
+    gc = linear(g.transpose(0, 2, 1), wn_legacy(w, p + "cond_layer"), w[p + "cond_layer.bias"], exact=True).transpose(0, 2, 1)  # [B, 2H*L, 1]
     for i in range(n_layers):
         x_in = conv1d(x, wn_legacy(w, p + f"in_layers.{i}"), w[p + f"in_layers.{i}.bias"], padding=(k - 1) // 2)
         g_l = gc[:, i * 2 * hidden : (i + 1) * 2 * hidden, :]
@@ -323,9 +347,26 @@ def convnext_block(x, s, w: W, p: str, k: int):
     h = conv1d(x, w[p + "dwconv.weight"], w[p + "dwconv.bias"], padding=(k - 1) // 2, groups=x.shape[1])
     h = adaptive_layer_norm(h.transpose(0, 2, 1), s, w, p + "norm", eps=1e-6)
     h = silu(linear(h, w[p + "pwconv1.weight"], w[p + "pwconv1.bias"]))
-    h = grn(h, w[p + "grn.gamma"], w[p + "grn.beta"])
-    h = linear(h, w[p + "pwconv2.weight"], w[p + "pwconv2.bias"])
+    if OPERAND_ROUND is None:
+        h = grn(h, w[p + "grn.gamma"], w[p + "grn.beta"])
+        h = linear(h, w[p + "pwconv2.weight"], w[p + "pwconv2.bias"])
+    else:
+        h = _grn_linear_rounded(h, w[p + "grn.gamma"], w[p + "grn.beta"], w[p + "pwconv2.weight"], w[p + "pwconv2.bias"])
     return (x + h.transpose(0, 2, 1)).astype(F32)
+
+
+def _grn_linear_rounded(u, gamma, beta, wt, b):
+    """GRN followed by a Linear in the 16-bit operand modes, with the HIP path's rounding points: GRN is the per-utterance
+    column scale s = 1 + gamma * nx plus the shift beta, so  W (u * s + beta) + b = (W * s) u + (W beta + b);  the scaled
+    weight and the un-scaled activation are what gets rounded (scale_weight_kernel / tile staging), the shift term is fp32."""
+    gx = np.sqrt((u.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    nx = (gx / (gx.mean(axis=-1, keepdims=True) + 1e-6)).astype(F32)  # [B,1,C]
+    sc = (gamma.reshape(1, 1, -1) * nx + F32(1.0)).astype(F32)
+    shift = (wt.astype(np.float64) @ beta.reshape(-1).astype(np.float64) + b).astype(F32)
+    out = np.empty(u.shape[:2] + (wt.shape[0],), F32)
+    for i in range(u.shape[0]):
+        out[i] = np.matmul(round_operand(u[i]), round_operand((wt * sc[i, 0][None, :]).astype(F32)).T) + shift
+    return out
 
 
 def circ_dist(a, b):
@@ -367,6 +408,26 @@ def align_branch(phase, hint, spec=None, return_bad=False):
     return (out, int((~ok).sum())) if return_bad else out
 
 
+def _output_conv(x, wt, b, padding):
+    """The 768 -> 1025 head convs.  In the 16-bit operand modes the HIP path runs bins 0..1023 on the matrix cores and
+    the Nyquist bin as an fp32 dot product (single_channel_conv_kernel), so only the former see rounded operands."""
+    if OPERAND_ROUND is None:
+        return conv1d(x, wt, b, padding=padding)
+    lo = conv1d(x, wt[:-1], b[:-1], padding=padding)
+    mode = OPERAND_ROUND
+    try:
+        _set_round(None)
+        hi = conv1d(x, wt[-1:], b[-1:], padding=padding)
+    finally:
+        _set_round(mode)
+    return np.concatenate([lo, hi], axis=1)
+
+
+def _set_round(mode):
+    global OPERAND_ROUND
+    OPERAND_ROUND = mode
+
+
 def generator_forward(mel, style, pitch, src_noise, init_phase, w: W, p: str = "generator.", cfg=None, return_intermediates=False, branch_hint=None):
     """Generator.forward (models/generator.py:402-438) with the two RNG draws explicit.  `energy` is
     accepted by the reference but unused.  Returns audio [B,1,75*T4], logamp, phase [B,1025,T4+1].
@@ -386,9 +447,9 @@ def generator_forward(mel, style, pitch, src_noise, init_phase, w: W, p: str = "
     xt = x.transpose(0, 2, 1)
     kk = w[p + "amp_output_conv.weight"].shape[2]
     la = adaptive_layer_norm(xt, style, w, p + "amp_final_layer_norm").transpose(0, 2, 1)
-    la = conv1d(np.concatenate([la, la_prior], axis=1), w[p + "amp_output_conv.weight"], w[p + "amp_output_conv.bias"], padding=(kk - 1) // 2)
+    la = _output_conv(np.concatenate([la, la_prior], axis=1), w[p + "amp_output_conv.weight"], w[p + "amp_output_conv.bias"], (kk - 1) // 2)
     ph = adaptive_layer_norm(xt, style, w, p + "phase_final_layer_norm").transpose(0, 2, 1)
-    ph = conv1d(np.concatenate([ph, ph_prior], axis=1), w[p + "phase_output_conv.weight"], w[p + "phase_output_conv.bias"], padding=(kk - 1) // 2)
+    ph = _output_conv(np.concatenate([ph, ph_prior], axis=1), w[p + "phase_output_conv.weight"], w[p + "phase_output_conv.bias"], (kk - 1) // 2)
     la = np.concatenate([la, la[:, :, -1:]], axis=2)  # F.pad replicate (generator.py:425-426)
     ph = np.concatenate([ph, ph[:, :, -1:]], axis=2)
     spec = np.exp(la)

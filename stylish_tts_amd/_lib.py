@@ -67,13 +67,14 @@ SIGNATURES = {
     "stts_duration_decode": (_I, [_P, _P, _I, _I, _P]),
     "stts_duration_to_alignment": (_I, [_P, _P, _I, _I, _P]),
     "stts_length_regulate": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I, _P, _I, _I, _P, _I, _P]),
+    "stts_set_precision": (_I, [_P, _I]),
     "stts_upsample4": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "stts_euler_step": (_I, [_P, _P, _P, C.c_float, C.c_int64]),
     "stts_to_time_major": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "stts_to_channel_major": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stts_profile_begin": (_I, []),
     "stts_profile_end": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "stts_op_conv1d": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I]),
+    "stts_op_conv1d": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I]),
     "stts_op_adain_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),
     "stts_op_mrf_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),
 }

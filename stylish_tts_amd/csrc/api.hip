@@ -48,6 +48,16 @@ void stts_ctx_destroy(stts_ctx* c) {
   delete c;
 }
 
+int stts_set_precision(stts_ctx* c, int precision) {
+  API_BEGIN
+  STTS_CHECK(c, "bad argument");
+  STTS_CHECK(precision >= 0 && precision <= 2, "precision must be STTS_PREC_F32, _BF16 or _F16");
+  STTS_CHECK(c->ready == 0 || precision == c->prec, "precision must be chosen before weights are finalized");
+  c->prec = precision;
+  return 0;
+  API_END
+}
+
 int stts_load_weight(stts_ctx* c, const char* name, const float* data, const int64_t* shape, int ndim) {
   API_BEGIN
   STTS_CHECK(c && name && data && shape && ndim >= 1 && ndim <= 4, "bad argument");
@@ -331,11 +341,13 @@ int stts_profile_end(void* stream, int* launches, double* total_ms, double* tota
 
 // ------------------------------------------------------------------------------------------------ test operators
 int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,
-                   const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile) {
+                   const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile, int precision) {
   API_BEGIN
   hipStream_t st = (hipStream_t)stream;
   STTS_CHECK(ldx % 32 == 0 && ldx >= cin, "op_conv1d: ldx must be a multiple of 32 covering cin");
+  STTS_CHECK(precision >= 0 && precision <= 2, "precision must be STTS_PREC_F32, _BF16 or _F16");
   stts_ctx tmp;  // only for allocation bookkeeping
+  tmp.prec = precision;
   HostTensor w;
   w.shape = {cout, cin, k};
   w.data.assign(w_host, w_host + (size_t)cout * cin * k);

@@ -303,8 +303,10 @@ __global__ void __launch_bounds__(256) grn_gx_kernel(const float* __restrict__ p
 
 // Wu[u][row][k] = W[row][k] * (gamma[k] * gx[u][k] / (mean_k gx[u][:] + 1e-6) + 1)   (W packed [Npad][kc], one tap)
 // every block recomputes the channel mean of its utterance (kc values, L2 resident) - no extra launch.
+// PREC != 0: the scaled copy is written rounded to bf16 / fp16 (the contraction's 16-bit operand mode).
+template <int PREC>
 __global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restrict__ W, const float* __restrict__ gx, int ld_gx,
-                                                           const float* __restrict__ gamma, float* __restrict__ Wu, int npad, int kc) {
+                                                           const float* __restrict__ gamma, void* __restrict__ Wu_, int npad, int kc) {
   __shared__ float red[4];
   const int u = blockIdx.y;
   float part = 0.f;
@@ -320,8 +322,9 @@ __global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restri
     const float4 w = reinterpret_cast<const float4*>(W)[i];
     const float4 g = *reinterpret_cast<const float4*>(gx + (long)u * ld_gx + k4);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + k4);
-    reinterpret_cast<float4*>(Wu + (long)u * npad * kc)[i] =
-        make_float4(w.x * (ga.x * g.x * inv + 1.f), w.y * (ga.y * g.y * inv + 1.f), w.z * (ga.z * g.z * inv + 1.f), w.w * (ga.w * g.w * inv + 1.f));
+    const f32x4 v = {w.x * (ga.x * g.x * inv + 1.f), w.y * (ga.y * g.y * inv + 1.f), w.z * (ga.z * g.z * inv + 1.f), w.w * (ga.w * g.w * inv + 1.f)};
+    if constexpr (PREC == PREC_F32) reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Wu_) + (long)u * npad * kc)[i] = v;
+    else reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(Wu_) + (long)u * npad * kc)[i] = pack4_16<PREC>(v);
   }
 }
 
@@ -497,6 +500,13 @@ __global__ void __launch_bounds__(256) euler_step_kernel(float* __restrict__ x, 
     const float p = dt * v[i];
     x[i] = x[i] + p;
   }
+}
+
+inline void launch_scale_weight(hipStream_t st, dim3 grid, int prec, const float* W, const float* gx, int ld_gx, const float* gamma, void* Wu, int npad,
+                                int kc) {
+  if (prec == PREC_BF16) hipLaunchKernelGGL(scale_weight_kernel<PREC_BF16>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);
+  else if (prec == PREC_F16) hipLaunchKernelGGL(scale_weight_kernel<PREC_F16>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);
+  else hipLaunchKernelGGL(scale_weight_kernel<PREC_F32>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);
 }
 
 }  // namespace stts

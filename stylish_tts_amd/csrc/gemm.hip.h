@@ -20,6 +20,7 @@
 // Up to 3 input segments accumulate into one output (conv + 1x1 shortcut; concat inputs), and the
 // epilogue fuses bias / activation / residual / gates so no extra pass over the output is needed.
 #pragma once
+#include <type_traits>
 #include <mutex>
 #include <map>
 #include <hip/hip_ext.h>
@@ -46,6 +47,7 @@ enum Epi {
 struct GemmSeg {
   const float* X;     // time-major activations
   const float* W;     // packed [Npad][ntaps][kc]
+  const unsigned short* W16;  // the same tensor rounded to bf16 / fp16 (16-bit operand modes)
   long w_utt_stride;  // floats between per-utterance copies of W (0: shared)
   int ldx, xcol0, kc, ntaps, dil, pad;
   int kreal;  // un-padded input channels (host side: algorithmic FLOP accounting only)
@@ -57,6 +59,7 @@ struct GemmArgs {
   const int* seg_off;  // device [n_utt + 1], rows
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
+  int prec;               // PREC_F32 / PREC_BF16 / PREC_F16 operands (every segment then carries W16)
   long long* dbg;         // block-timeline records (only written when built with -DSTTS_GEMM_TRACE; tools/gemm_bench.py)
   const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
   int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
@@ -97,18 +100,54 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// 16-bit operand modes (PREC 1 = bf16, 2 = fp16): activations stay fp32 in HBM and are rounded (RNE) when a tile is
+// staged into LDS, weights are stored pre-rounded ([cout][tap][cin] 16-bit), products accumulate in fp32 on
+// v_mfma_f32_32x32x16_{bf16,f16}.  A 32-channel K chunk is then 64 bytes per tile row (4 slots of 16 bytes, swizzled by
+// (row >> 2) & 3) and two MFMAs instead of sixteen.
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int PREC>
+__device__ __forceinline__ u32x2 pack4_16(const f32x4 v) {
+  u32x2 r;
+  if constexpr (PREC == PREC_BF16) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2));
+  } else {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2));
+  }
+  return r;
+}
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(const f32x4 a, const f32x4 b, const f32x16 c) {
+  if constexpr (PREC == PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
 // partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
 // have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
+  constexpr bool B16 = PREC != PREC_F32;
+  static_assert(!(B16 && GLDS), "16-bit operands use the register staging path");
   static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
   constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
   constexpr int TR = WR / 32, TC = WC / 32;
-  constexpr int XL = BN * 8 / NT, WL = BM * 8 / NT;
+  constexpr int XL = BN * 8 / NT;
+  constexpr int WL = B16 ? (BM * 4 + NT - 1) / NT : BM * 8 / NT;  // 16-byte W loads per thread per tile
   static_assert(WR % 32 == 0 && WC % 32 == 0, "wave tile must be a multiple of 32x32");
-  static_assert((BN * 8) % NT == 0 && (BM * 8) % NT == 0, "tile loads must divide over the block");
+  static_assert((BN * 8) % NT == 0 && (B16 || (BM * 8) % NT == 0), "tile loads must divide over the block");
   static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
   __shared__ f32x4 lds[2 * (BN + BM) * 8];
 
@@ -163,6 +202,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   int s = 0, tap = 0, chunk = 0;
   const float* gX = a.seg[0].X + a.seg[0].xcol0;
   const float* gW = a.seg[0].W + (long)utt * a.seg[0].w_utt_stride + (long)m0 * a.seg[0].ntaps * a.seg[0].kc;
+  const unsigned short* gW16 = B16 ? a.seg[0].W16 + (long)utt * a.seg[0].w_utt_stride + (long)m0 * a.seg[0].ntaps * a.seg[0].kc : nullptr;
   int g_ldx = a.seg[0].ldx, g_kc = a.seg[0].kc, g_ntaps = a.seg[0].ntaps, g_dil = a.seg[0].dil, g_pad = a.seg[0].pad;
   const int nseg = a.nseg;
 
@@ -183,7 +223,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int idx = tid + i * NT;
-      woff[i] = (unsigned)(((idx >> 3) * wrow + (idx & 7) * 4) * 4);
+      if constexpr (B16) woff[i] = (unsigned)((min(idx >> 2, BM - 1) * wrow + (idx & 3) * 8) * 2);  // 8 x 16-bit per load
+      else woff[i] = (unsigned)(((idx >> 3) * wrow + (idx & 7) * 4) * 4);
     }
   };
   seg_offsets();
@@ -191,7 +232,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     const int shift = (tap - g_pad) * g_dil;
     const bool hot = a.tune & 16;  // ablation only: every tile read hits the same few KB (L1/L2 resident) -> wrong results
     const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + (hot ? 0 : chunk * 32));
-    const char* wb = reinterpret_cast<const char*>((hot ? a.seg[0].W : gW) + (hot ? 0 : tap * g_kc + chunk * 32));
+    const char* wb = B16 ? reinterpret_cast<const char*>(gW16 + tap * g_kc + chunk * 32)
+                         : reinterpret_cast<const char*>((hot ? a.seg[0].W : gW) + (hot ? 0 : tap * g_kc + chunk * 32));
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
@@ -218,11 +260,30 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
       gX = n.X + n.xcol0;
       gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+      if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
       g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
       seg_offsets();
     }
   };
   auto lstore = [&](const RegSet& rs, int b) {
+    if constexpr (B16) {
+      f32x4* Xs = lds + b * (BN + BM) * 4;  // 4 x 16-byte slots (64 bytes) per row
+      f32x4* Ws = Xs + BN * 4;
+      u32x2* Xh = reinterpret_cast<u32x2*>(Xs);
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx >> 3, sl = idx & 7;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        Xh[(r * 4 + ((sl >> 1) ^ ((r >> 2) & 3))) * 2 + (sl & 1)] = pack4_16<PREC>(rs.ok[i] ? rs.x[i] : z);
+      }
+#pragma unroll
+      for (int i = 0; i < WL; ++i) {
+        const int idx = tid + i * NT;
+        const int n = idx >> 2, c = idx & 3;
+        if (BM * 4 % NT == 0 || idx < BM * 4) Ws[n * 4 + (c ^ ((n >> 2) & 3))] = rs.w[i];
+      }
+    } else {
     f32x4* Xs = lds + b * (BN + BM) * 8;
     f32x4* Ws = Xs + BN * 8;
 #pragma unroll
@@ -237,6 +298,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       const int idx = tid + i * NT;
       const int n = idx >> 3, sl = idx & 7;
       Ws[n * 8 + (sl ^ ((n >> 1) & 7))] = rs.w[i];
+    }
     }
   };
 
@@ -255,6 +317,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
         gX = n.X + n.xcol0;
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+        if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+      if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
         seg_offsets();
       }
@@ -286,6 +350,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, wb[j].z, acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, wb[j].w, acc[i][j], 0, 0, 0);
       }
+  };
+
+  // 16-bit operands: kk = 0, 1 are the two 16-channel halves of the chunk; lanes 0-31 / 32-63 supply k 0-7 / 8-15
+  auto mma_step16 = [&](int b, int kk) {
+    const f32x4* Xs = lds + b * (BN + BM) * 4;
+    const f32x4* Ws = Xs + BN * 4;
+    const int slot = 2 * kk + lh;
+    f32x4 xa[TR], wb[TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int r = wn * WR + i * 32 + l31;
+      xa[i] = Xs[r * 4 + (slot ^ ((r >> 2) & 3))];
+    }
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      const int c = wm * WC + j * 32 + l31;
+      wb[j] = Ws[c * 4 + (slot ^ ((c >> 2) & 3))];
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j) acc[i][j] = mfma16<PREC>(xa[i], wb[j], acc[i][j]);
   };
 
   if constexpr (GLDS) {
@@ -331,6 +417,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
         gX = n.X + n.xcol0;
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+        if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+      if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
       }
     };
@@ -364,7 +452,18 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   auto iter = [&](int it, RegSet& nset) {
     const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
     const f32x4* Ws = Xs + BN * 8;
-    if constexpr (KSPLIT == 1) {
+    if constexpr (B16) {
+      if constexpr (KSPLIT == 1) {
+        mma_step16(it & 1, 0);
+        lstore(nset, (it + 1) & 1);
+        gload(nset);
+        mma_step16(it & 1, 1);
+      } else {
+        mma_step16(it & 1, kg);
+        lstore(nset, (it + 1) & 1);
+        gload(nset);
+      }
+    } else if constexpr (KSPLIT == 1) {
       mma_step(Xs, Ws, 0);
       if (!(a.tune & 4)) lstore(nset, (it + 1) & 1);
       mma_step(Xs, Ws, 1);
@@ -625,17 +724,17 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
     else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                             \
   } while (0)
 
-template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false>
+template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = PREC_F32>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
   switch (epi) {
-    case EPI_STORE: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL>), grid, block, st, e0, e1, a); break;
-    case EPI_SPLIT_ACC: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL>), grid, block, st, e0, e1, a); break;
+    case EPI_STORE: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR>), grid, block, st, e0, e1, a); break;
+    case EPI_SPLIT_ACC: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL, PR>), grid, block, st, e0, e1, a); break;
     default:
       if constexpr (BM / WM >= 64) {
-        if (epi == EPI_GATE) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS, GL>), grid, block, st, e0, e1, a);
-        else if (epi == EPI_COUPLE) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS, GL>), grid, block, st, e0, e1, a);
-        else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, GL>), grid, block, st, e0, e1, a);
+        if (epi == EPI_GATE) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_GATE, KS, GL, PR>), grid, block, st, e0, e1, a);
+        else if (epi == EPI_COUPLE) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_COUPLE, KS, GL, PR>), grid, block, st, e0, e1, a);
+        else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, GL, PR>), grid, block, st, e0, e1, a);
       }
       break;
   }
@@ -701,15 +800,29 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     e0 = prof.next();
     e1 = prof.next();
   }
-  switch (tile) {
-    case 2: launch_cfg<128, 64, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
-    case 5: launch_cfg<128, 128, 4, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;    // 8 waves per block
-    case 6: launch_cfg<128, 64, 4, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;     // 8 waves, 64-row tiles (no row-padding waste at T4 = 960)
-    case 11: launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // LDS-DMA staging, 8 waves
-    case 13: launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // LDS-DMA staging, 64-row tile
-    case 8: launch_cfg<128, 128, 4, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
-    default: launch_cfg<128, 32, 2, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+  auto dispatch = [&](auto prec_tag) {
+    constexpr int PR = decltype(prec_tag)::value;
+    switch (tile) {
+      case 2: launch_cfg<128, 64, 2, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+      case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
+      case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
+      case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
+      case 11:
+        if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves
+        break;
+      case 13:
+        if constexpr (PR == PREC_F32) launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 64-row tile
+        break;
+      default: launch_cfg<128, 32, 2, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    }
+  };
+  if (a.prec != PREC_F32) {
+    for (int i = 0; i < a.nseg; ++i) STTS_CHECK(a.seg[i].W16 != nullptr, "conv_gemm: 16-bit operand mode without 16-bit weights (segment %d)", i);
+    STTS_CHECK(tile != 11 && tile != 13, "conv_gemm: LDS-DMA tiles are fp32 only");
   }
+  if (a.prec == PREC_BF16) dispatch(std::integral_constant<int, PREC_BF16>{});
+  else if (a.prec == PREC_F16) dispatch(std::integral_constant<int, PREC_F16>{});
+  else dispatch(std::integral_constant<int, PREC_F32>{});
   if (as.ksplit > 1) {
     const long work = (long)a.rows_total * ((a.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), 0, st, as.partial, as.ksplit,

@@ -25,6 +25,8 @@ struct HostTensor {
 
 struct PackedConv {
   float* W = nullptr;
+  unsigned short* W16 = nullptr;  // bf16 / fp16 copy (16-bit operand modes), same layout
+  int prec = 0;                   // PREC_* the copy was rounded to
   float* bias = nullptr;
   int npad = 0, N = 0, kc = 0, ntaps = 1;
   int cin_real = 0, rows_real = 0;  // un-padded sizes (FLOP accounting)
@@ -94,6 +96,7 @@ struct stts_ctx {
   std::vector<void*> allocs;
   int* d_err = nullptr;
   int ready = 0;  // STTS_W_* components finalized
+  int prec = 0;   // contraction operand precision (stts::PREC_*), fixed before the first finalize
   // shared tables
   float* hann = nullptr;      // periodic Hann(win)
   float2* twiddle = nullptr;  // exp(-2 pi i m / n_fft), m < n_fft/2
@@ -180,6 +183,20 @@ inline int get_weight(stts_ctx* c, const std::string& p, HostTensor* w) {
 
 // Pack rows of a [cout][cin][k] weight: out[n'][tap][ci] for ci in [0,kc) taking input channel cin_lo+ci.
 // row_of[n'] = source row (or -1 for zero padding); bias follows the same row order.
+// host-side round-to-nearest-even conversions for the 16-bit weight copies
+inline unsigned short f32_to_bf16(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline unsigned short f32_to_f16(float f) {
+  const _Float16 h = (_Float16)f;  // IEEE RNE, saturates to inf
+  unsigned short r;
+  memcpy(&r, &h, 2);
+  return r;
+}
+
 inline int pack_rows(stts_ctx* c, const HostTensor& w, const HostTensor* bias, const std::vector<int>& row_of, int cin_lo, int cin_n,
                      int kc, int N, PackedConv* out, float scale = 1.0f) {
   const int cin = (int)w.shape[1], k = (int)w.shape[2];
@@ -194,6 +211,17 @@ inline int pack_rows(stts_ctx* c, const HostTensor& w, const HostTensor* bias, c
   }
   STTS_TRY(dev_upload(c, pw, &out->W));
   STTS_TRY(dev_upload(c, pb, &out->bias));
+  out->prec = c->prec;
+  out->W16 = nullptr;
+  if (c->prec != PREC_F32) {
+    std::vector<unsigned short> h(pw.size());
+    for (size_t i = 0; i < pw.size(); ++i) h[i] = c->prec == PREC_BF16 ? f32_to_bf16(pw[i]) : f32_to_f16(pw[i]);
+    void* d = nullptr;
+    STTS_HIP(hipMalloc(&d, h.size() * sizeof(unsigned short)));
+    c->allocs.push_back(d);
+    STTS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    out->W16 = (unsigned short*)d;
+  }
   out->npad = npad;
   out->N = N;
   out->kc = kc;
@@ -460,6 +488,8 @@ inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, cons
   GemmSeg& g = a.seg[i];
   g.X = X;
   g.W = w.W;
+  g.W16 = w.W16;
+  if (i == 0) a.prec = w.prec;
   g.w_utt_stride = 0;
   g.ldx = ldx;
   g.xcol0 = xcol0;
@@ -603,6 +633,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   if (z_prior_out) STTS_HIP(hipMemcpyAsync(z_prior_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
   // reversed(flows) = Flip, layer 7, Flip, layer 6, ..., Flip, layer 0: after k flips the roles of the halves swap,
   // so layer f reads half p = (f odd) and updates the other half in place; after layer 0 the order is natural.
+  auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
   for (int f = 7; f >= 0; --f) {
     const FlowLayerW& L = c->flow[f];
     const int p = f & 1;
@@ -619,18 +650,18 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       // applies the block's post projection + reverse coupling and the next block's pre projection to its rows
       WnArgs w;
       w.Hin = hcur; w.Hout = i < 3 ? hnext : nullptr; w.Out = outf; w.seg_off = s.dev;
-      w.Win = L.in[i].W; w.bin = L.in[i].bias; w.Wrs = L.rs[i].W; w.brs = L.rs[i].bias;
+      w.Win = wptr(L.in[i]); w.bin = L.in[i].bias; w.Wrs = wptr(L.rs[i]); w.brs = L.rs[i].bias;
       w.gate = cond; w.ld_gate = c->flow_style.ld(); w.gcol0 = L.cond_col0 + i * 2 * fh;
       w.n_rs = L.rs[i].N; w.out_acc = i > 0;
-      w.tail = 0; w.Wproj = w.bproj = w.Wpre = w.bpre = nullptr; w.Z = w.Hpre = nullptr; w.ldz = w.zcol0 = 0;
+      w.tail = 0; w.Wproj = w.Wpre = nullptr; w.bproj = w.bpre = nullptr; w.Z = w.Hpre = nullptr; w.ldz = w.zcol0 = 0;
       double extra = 0;
       if (i == 3) {
         w.tail = f > 0 ? 2 : 1;
-        w.Wproj = L.proj.W; w.bproj = L.proj.bias; w.Z = z; w.ldz = fh; w.zcol0 = (1 - p) * half;
+        w.Wproj = wptr(L.proj); w.bproj = L.proj.bias; w.Z = z; w.ldz = fh; w.zcol0 = (1 - p) * half;
         extra = 2.0 * (double)R * fh * fh;
         if (f > 0) {
           const FlowLayerW& nx = c->flow[f - 1];
-          w.Wpre = nx.pre.W; w.bpre = nx.pre.bias; w.Hpre = hf;  // layer 3 reads hf2; hf is free and is the next block's h
+          w.Wpre = wptr(nx.pre); w.bpre = nx.pre.bias; w.Hpre = hf;  // layer 3 reads hf2; hf is free and is the next block's h
           extra += 2.0 * (double)R * fh * half;
         }
       }
@@ -641,7 +672,10 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         e1 = prof.next();
         prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh) + extra);
       }
-      STTS_LAUNCH_TIMED(wn_layer_kernel<4>, dim3(ceil_div(ml, 32), s.n_utt), dim3(1024), st, e0, e1, w);
+      const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
+      if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_BF16>, wgrid, dim3(1024), st, e0, e1, w);
+      else if (c->prec == PREC_F16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F16>, wgrid, dim3(1024), st, e0, e1, w);
+      else STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F32>, wgrid, dim3(1024), st, e0, e1, w);
       std::swap(hcur, hnext);
     }
     STTS_HIP(hipGetLastError());
@@ -748,10 +782,11 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
     hipLaunchKernelGGL(grn_gx_kernel, dim3(ceil_div(inter, 256), s.n_utt), dim3(256), 0, st, part, inter, ss_stride, s.dev, inter, gscale, inter);
-    hipLaunchKernelGGL(scale_weight_kernel, dim3(128, s.n_utt), dim3(256), 0, st, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
+    launch_scale_weight(st, dim3(128, s.n_utt), B.pw2.prec, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, U, inter, 0, B.pw2);
     b.seg[0].W = w2u;
+    b.seg[0].W16 = reinterpret_cast<const unsigned short*>(w2u);
     b.seg[0].w_utt_stride = (long)B.pw2.npad * B.pw2.kc;
     b.N = h; b.bias = B.pw2.bias; b.Y = nxt; b.ldy = h; b.R = cur; b.ldr = h;
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.pw2.npad, s.n_utt, ml));

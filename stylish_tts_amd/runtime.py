@@ -50,7 +50,13 @@ class Segments:
 class HipModel:
     """Owns a stts_ctx.  weights: {module name: {state_dict key: array}} for the five inference modules."""
 
-    def __init__(self, cfg=None, device: int = 0):
+    PRECISIONS = {"f32": 0, "bf16": 1, "f16": 2}
+
+    def __init__(self, cfg=None, device: int = 0, precision: str = "f32"):
+        """precision: operand precision of the contractions ("f32" = the reference's arithmetic; "bf16" / "f16" round
+        the matrix-core operands, fp32 accumulate; include/stylish_hip.h:stts_set_precision)."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         if not torch.cuda.is_available():
             raise RuntimeError("HipModel needs a GPU (MI355X); there is no CPU fallback in the product path")
         self.lib = _lib.load()
@@ -60,6 +66,8 @@ class HipModel:
         h = C.c_void_p()
         _lib.check(self.lib.stts_ctx_create(C.byref(self._dims), device, C.byref(h)))
         self.ctx = h
+        self.precision = precision
+        _lib.check(self.lib.stts_set_precision(self.ctx, self.PRECISIONS[precision]))
         self._ws: Optional[torch.Tensor] = None
 
     def close(self):
@@ -162,14 +170,15 @@ class HipModel:
         _lib.check(self.lib.stts_to_channel_major(_stream(), _ptr(x), x.shape[1], B, Cc, T, _ptr(y)))
         return y
 
-    def op_conv1d(self, seg: Segments, x, cin, w: np.ndarray, bias: Optional[np.ndarray], dil=1, act=0, force_tile=0):
+    def op_conv1d(self, seg: Segments, x, cin, w: np.ndarray, bias: Optional[np.ndarray], dil=1, act=0, force_tile=0, precision: Optional[str] = None):
         cout, _, k = w.shape
         ldy = (cout + 31) // 32 * 32
         y = torch.zeros(seg.rows, ldy, dtype=torch.float32, device=self.device)
         w = np.ascontiguousarray(w, np.float32)
         b = None if bias is None else np.ascontiguousarray(bias, np.float32)
         _lib.check(self.lib.stts_op_conv1d(_stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], cin, w.ctypes.data_as(C.c_void_p),
-                                           None if b is None else b.ctypes.data_as(C.c_void_p), cout, k, dil, act, _ptr(y), ldy, force_tile))
+                                           None if b is None else b.ctypes.data_as(C.c_void_p), cout, k, dil, act, _ptr(y), ldy, force_tile,
+                                           self.PRECISIONS[precision or self.precision]))
         return y
 
     def op_adain_block(self, prefix: str, seg: Segments, x, cin, cout, style):

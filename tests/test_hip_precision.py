@@ -1,0 +1,151 @@
+"""16-bit operand modes of the contractions (BASELINE cfg3 bf16 / cfg5 fp16; include/stylish_hip.h:stts_set_precision).
+
+Two bars per mode:
+  * against the oracle with the SAME rounding points (operands of every matrix-core contraction rounded to nearest-even,
+    fp32 products and sums): tight, only summation order differs;
+  * against the fp32 reference goldens: the stated 16-bit tolerance (the reference itself only runs fp32).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def segs(lengths):
+    from stylish_tts_amd.runtime import Segments
+
+    return Segments(lengths, torch.device("cuda", 0))
+
+
+@pytest.fixture(scope="module")
+def hip32(cfg):
+    from stylish_tts_amd.runtime import HipModel
+
+    m = HipModel(cfg, 0)
+    yield m
+    m.close()
+
+
+@pytest.fixture()
+def rounded_oracle():
+    from oracle import stylish_oracle as O
+
+    def use(mode):
+        O.OPERAND_ROUND = mode
+        return O
+
+    yield use
+    O.OPERAND_ROUND = None
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize(
+    "cin,cout,k,dil,lengths,tile",
+    [
+        (64, 128, 1, 1, [40], 3),
+        (578, 512, 3, 1, [200, 37, 129], 0),
+        (578, 512, 3, 1, [200, 37, 129], 2),
+        (578, 512, 3, 1, [200, 37, 129], 5),
+        (578, 512, 3, 1, [200, 37, 129], 6),
+        (578, 512, 3, 1, [200, 37, 129], 8),
+        (96, 1025, 7, 1, [50, 333], 0),
+        (64, 130, 7, 3, [77, 5], 0),
+        (1536, 512, 1, 1, [130], 0),
+    ],
+)
+def test_conv1d_16bit_matches_rounded_oracle(hip32, rounded_oracle, prec, cin, cout, k, dil, lengths, tile):
+    from stylish_tts_amd import synth
+
+    O = rounded_oracle(prec)
+    s = segs(lengths)
+    ld = (cin + 31) // 32 * 32
+    w = (synth.normal(f"p.w.{cin}.{cout}.{k}", (cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    b = synth.normal(f"p.b.{cout}", (cout,))
+    xs = [synth.normal(f"p.x.{i}.{L}", (1, cin, L)) for i, L in enumerate(lengths)]
+    x = np.zeros((s.rows, ld), np.float32)
+    for i, xi in enumerate(xs):
+        x[s.host[i] : s.host[i + 1], :cin] = xi[0].T
+    y = hip32.op_conv1d(s, dev(x), cin, w, b, dil=dil, force_tile=tile, precision=prec).cpu().numpy()
+    y32 = hip32.op_conv1d(s, dev(x), cin, w, b, dil=dil, force_tile=tile).cpu().numpy()
+    for i, xi in enumerate(xs):
+        ref = O.conv1d(xi, w, b, padding=(k - 1) // 2 * dil, dilation=dil)[0].T
+        got = y[s.host[i] : s.host[i + 1], :cout]
+        scale = np.abs(ref).max()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 2e-5 * scale, (prec, i, np.abs(got - ref).max(), scale)
+        # and the mode really rounds: it differs from the fp32 contraction by about one operand ulp
+        d32 = np.abs(got - y32[s.host[i] : s.host[i + 1], :cout]).max() / scale
+        assert (1e-4 if prec == "f16" else 1e-3) < d32 < (3e-3 if prec == "f16" else 3e-2), (prec, d32)
+
+
+def _ragged_case(tag, lens):
+    from stylish_tts_amd import synth
+
+    per = []
+    for i, L in enumerate(lens):
+        per.append(
+            dict(
+                asr=synth.normal(f"{tag}.asr{i}", (1, 128, L)),
+                pitch=synth.pitch_curve(f"{tag}.p{i}", 1, L),
+                energy=(synth.uniform(f"{tag}.e{i}", (1, L)) * 2 + 2).astype(np.float32),
+                style=(synth.normal(f"{tag}.s{i}", (1, 64)) * 0.7).astype(np.float32),
+                nz=synth.path_noise(f"{tag}{i}", 1, L),
+            )
+        )
+    return per
+
+
+# waveform max-abs tolerances of the 16-bit operand modes (fp32 accumulation; |audio| < 1):
+#   vs the oracle with the same rounding points   vs the fp32 oracle (what rounding the operands costs)
+TOL = {"bf16": (8e-3, 1.2e-2), "f16": (1.2e-3, 1.5e-3)}  # measured: bf16 3.8e-3 / 4.5e-3, f16 4.8e-4 / 5.8e-4
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_frame_path_16bit_ragged_batch(cfg, weights, rounded_oracle, prec):
+    """cfg3 / cfg5 arithmetic on a mixed-length batch: decoder -> prior/flow -> vocoder with 16-bit matrix-core operands."""
+    from stylish_tts_amd.runtime import HipModel
+
+    hip = HipModel(cfg, 0, precision=prec)
+    hip.load_weights({"speech_predictor": weights["speech_predictor"]}, which=7)
+    w = weights["speech_predictor"]
+    lens = [40, 131, 76]
+    s = segs(lens)
+    per = _ragged_case("q", lens)
+    init_phase = per[0]["nz"]["init_phase"]
+    cat = lambda k: np.concatenate([p[k][0].T if p[k].ndim == 3 else p[k][0] for p in per])  # noqa: E731
+    asr, pitch, energy = dev(cat("asr")), dev(cat("pitch")), dev(cat("energy"))
+    style = dev(np.concatenate([p["style"] for p in per]))
+    pn = dev(np.concatenate([p["nz"]["prior_noise"][0].T for p in per]))
+    sn = dev(np.concatenate([p["nz"]["src_noise"].reshape(-1) for p in per]))
+    x = hip.decoder(s, asr, pitch, energy, style)
+    mel = hip.prior_flow(s, x, style, pn)
+    spec, phase = hip.harmonic_stft(s, pitch, sn, dev(init_phase.reshape(-1)), batch_scope=False)
+    audio = hip.vocoder(s, mel, style, spec, phase).cpu().numpy()
+    fused = hip.frame_path(s, asr, pitch, energy, style, pn, sn, dev(init_phase.reshape(-1)), batch_scope=False).cpu().numpy()
+    assert np.array_equal(fused, audio)
+    ph_np, x_np, mel_np = phase.cpu().numpy(), x.cpu().numpy(), mel.cpu().numpy()
+    assert np.isfinite(audio).all()
+    errs = []
+    for i, (L, p) in enumerate(zip(lens, per)):
+        nz = dict(p["nz"], init_phase=init_phase)
+        hint = ph_np[s.host[i] : s.host[i + 1], :1025].T[None]
+        sl = slice(75 * s.host[i], 75 * s.host[i + 1])
+        O = rounded_oracle(prec)
+        xd = O.decoder_forward(p["asr"], p["pitch"], p["energy"], p["style"], w)
+        ex = np.abs(x_np[s.host[i] : s.host[i + 1], :512].T - xd[0]).max() / np.abs(xd).max()
+        a_r, _, _ = O.frame_path(p["asr"], p["pitch"], p["energy"], p["style"], nz, w, branch_hint=hint)
+        O = rounded_oracle(None)
+        a_f, _, _ = O.frame_path(p["asr"], p["pitch"], p["energy"], p["style"], nz, w, branch_hint=hint)
+        errs.append((ex, np.abs(audio[sl] - a_r[0, 0]).max(), np.abs(audio[sl] - a_f[0, 0]).max()))
+    print(prec, "decoder err / audio vs rounded oracle / audio vs fp32 oracle:", errs)
+    hip.close()
+    for ex, er, ef in errs:
+        assert er < TOL[prec][0], (prec, errs)
+        assert ef < TOL[prec][1], (prec, errs)
