@@ -495,6 +495,16 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   }
   PackedConv pc;
   pc.W = W; pc.bias = B; pc.npad = npad; pc.N = cout; pc.kc = kc; pc.ntaps = k; pc.cin_real = cin; pc.rows_real = cout;
+  unsigned short* W16 = nullptr;
+  if (tune & 384) {  // bit 7: bf16 operands, bit 8: fp16 operands
+    std::vector<unsigned short> h16((size_t)npad * k * kc);
+    uint32_t s2 = 777;
+    for (auto& v : h16) { s2 = s2 * 1664525u + 1013904223u; v = f32_to_bf16(((s2 >> 8) & 0xFFFF) / 32768.0f - 1.0f); }
+    STTS_HIP(hipMalloc(&W16, h16.size() * 2));
+    STTS_HIP(hipMemcpy(W16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+    pc.W16 = W16;
+    pc.prec = (tune & 128) ? PREC_BF16 : PREC_F16;
+  }
   Seg s{n_utt, h.data(), so};
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, X, kc, 0, pc);
@@ -585,6 +595,7 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
     (void)hipFree(dbg);
   }
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(B); (void)hipFree(so);
+  if (W16) (void)hipFree(W16);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;
   API_END

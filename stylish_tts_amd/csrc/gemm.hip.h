@@ -770,7 +770,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       // one 128x128 tile per CU (B = 8: every 512-channel layer): two K-groups of 8 waves share each staged tile, which
       // keeps the matrix pipes busier than 8 waves do (118 vs 125.5 us) and beats cutting K over two blocks plus the
       // reduce pass (131 us)
-      if (tile == 5 && blocks128 <= 256) tile = 8;
+      // (fp32 only: with 16-bit operands the loop is staging-bound and 8 waves are faster, 34 vs 40 us)
+      if (tile == 5 && blocks128 <= 256 && a.prec == PREC_F32) tile = 8;
     }
   }
   // (intra-block K-split, tiles 8-10, and 2-wave tiles measured no better than these at any layer shape: every
@@ -784,7 +785,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     const long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
     int iters = 0;
     for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
-    int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, 512 / std::max<long>(blocks, 1)));
+    // (16-bit operands: a contraction that already has one tile per CU is shorter than the reduce pass it would add)
+    int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, (a.prec == PREC_F32 ? 512 : 255) / std::max<long>(blocks, 1)));
     if (ksp >= 2) {
       float* part = splitk_scratch(st, (size_t)ksp * a.rows_total * npad * sizeof(float));
       if (part) {
