@@ -57,6 +57,9 @@ struct GemmArgs {
   GemmSeg seg[3];
   int nseg;
   const int* seg_off;  // device [n_utt + 1], rows
+  const int* seg_host;  // the same offsets on the host (launcher only): exact tile counts for mixed-length batches
+  int n_utt;
+  int compact;          // grid.y enumerates only the row tiles that exist (sum over utterances), grid.z = split-K slice
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
   int prec;               // PREC_F32 / PREC_BF16 / PREC_F16 operands (every segment then carries W16)
@@ -165,7 +168,40 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     bz = id / (gx * gy);
   }
   const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
-  const int utt = bz / ksplit, ks = bz % ksplit;
+  int utt, ks;
+  if (a.compact) {
+    // Mixed-length batches: a (row tile, utterance) grid is mostly empty blocks and, worse, the contiguous per-XCD ranges
+    // above would give whole utterances to one XCD (long ones = hot XCDs).  grid.y instead counts the row tiles that
+    // exist; every wave finds its utterance with a prefix sum of tiles-per-utterance over its lanes.
+    ks = bz;
+    const int t = by, lane_ = threadIdx.x & 63;
+    utt = a.n_utt - 1;
+    int base = 0, local = 0;
+    bool done = false;
+    for (int u0 = 0; u0 < a.n_utt && !done; u0 += 64) {
+      const int u = u0 + lane_;
+      const int tiles = u < a.n_utt ? (a.seg_off[u + 1] - a.seg_off[u] + BN - 1) / BN : 0;
+      int incl = tiles;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane_ >= d) incl += v;
+      }
+      const int excl = incl - tiles;
+      const unsigned long long hit = __ballot(t >= base + excl && t < base + incl);
+      if (hit) {
+        const int src = __ffsll((long long)hit) - 1;
+        utt = u0 + src;
+        local = t - base - __shfl(excl, src, 64);
+        done = true;
+      }
+      base += __shfl(incl, 63, 64);
+    }
+    by = local;
+  } else {
+    utt = bz / ksplit;
+    ks = bz % ksplit;
+  }
   const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
   const int row0 = lo + by * BN;
   if (row0 >= hi) return;
@@ -727,6 +763,11 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = PREC_F32>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
+  if (a.compact) {
+    int tiles = 0;
+    for (int u = 0; u < a.n_utt; ++u) tiles += ceil_div(a.seg_host[u + 1] - a.seg_host[u], BN);
+    grid = dim3(npad / BM, tiles, a.ksplit > 1 ? a.ksplit : 1);
+  }
   switch (epi) {
     case EPI_STORE: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR>), grid, block, st, e0, e1, a); break;
     case EPI_SPLIT_ACC: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL, PR>), grid, block, st, e0, e1, a); break;
@@ -750,7 +791,12 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   }
   // Tile choice from tools/gemm_bench.py on MI355X (B = 8 x 960 rows): 128x128 with 8 waves once that fills the chip
   // (>= 200 blocks), 128(cout) x 64(rows) with 4 waves for the mid-size layers, 128 x 32 for the small ones.
-  const long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
+  long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
+  if (a.seg_host) {
+    long t = 0;
+    for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], 128);
+    blocks128 = (long)(npad / 128) * t;
+  }
   int tile = force_tile;
   const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
   if (tile == 0) {
@@ -761,9 +807,15 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       // ceil(blocks / 256 CUs) block-times however many blocks are co-resident.  288 blocks of 128x128 (a 3.5 s batch
       // of 8) cost two rounds; 576 of 128x64 cost three half-sized ones.  (Block-timeline trace, profiles/.)
       const int mt = npad / 128;
-      const bool uniform = (long)max_rows * n_utt == a.rows_total;
       auto rounds_cost = [&](int bn, double penalty) {
-        const double nb = uniform ? (double)mt * n_utt * ceil_div(max_rows, bn) : mt * ((double)a.rows_total / bn + 0.5 * n_utt);
+        double nb;
+        if (a.seg_host) {
+          long t = 0;
+          for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], bn);
+          nb = (double)mt * t;
+        } else {
+          nb = (double)mt * n_utt * ceil_div(max_rows, bn);
+        }
         return std::ceil(nb / 256.0) * bn * penalty;
       };
       tile = rounds_cost(128, 1.0) <= rounds_cost(64, 1.03) ? 5 : 6;
@@ -780,9 +832,16 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
   GemmArgs as = a;
   as.ksplit = 1;
+  as.n_utt = n_utt;
+  as.compact = a.seg_host != nullptr && (long)max_rows * n_utt != a.rows_total;  // mixed lengths: enumerate existing row tiles only
   if (force_tile == 0 && epi == EPI_STORE && !a.sumsq_part && tile != 8) {
     const int bn = tile == 5 ? 128 : (tile == 3 ? 32 : 64);
-    const long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
+    long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
+    if (as.compact) {
+      long t = 0;
+      for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], bn);
+      blocks = (long)(npad / 128) * t;
+    }
     int iters = 0;
     for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
     // (16-bit operands: a contraction that already has one tile per CU is shorter than the reduce pass it would add)

@@ -479,6 +479,8 @@ inline GemmArgs gemm_args(const Seg& s) {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.seg_off = s.dev;
+  a.seg_host = s.host;
+  a.n_utt = s.n_utt;
   a.rows_total = s.rows();
   a.alpha = 1.0f;
   a.zeros = zero_page();
