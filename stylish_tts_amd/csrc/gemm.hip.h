@@ -60,6 +60,7 @@ struct GemmArgs {
   const int* seg_host;  // the same offsets on the host (launcher only): exact tile counts for mixed-length batches
   int n_utt;
   int compact;          // grid.y enumerates only the row tiles that exist (sum over utterances), grid.z = split-K slice
+  int tile0, tiles_y;   // compact: this launch covers global row tiles [tile0, tile0 + tiles_y)
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
   int prec;               // PREC_F32 / PREC_BF16 / PREC_F16 operands (every segment then carries W16)
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     // above would give whole utterances to one XCD (long ones = hot XCDs).  grid.y instead counts the row tiles that
     // exist; every wave finds its utterance with a prefix sum of tiles-per-utterance over its lanes.
     ks = bz;
-    const int t = by, lane_ = threadIdx.x & 63;
+    const int t = by + a.tile0, lane_ = threadIdx.x & 63;
     utt = a.n_utt - 1;
     int base = 0, local = 0;
     bool done = false;
@@ -664,12 +665,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 
 // Finishes a block-level split-K contraction: Y = (act(sum_ks partial[ks] + bias) [+ R]) * alpha, partials summed in a
 // fixed order (deterministic).  One thread per (row, 4 columns).
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int rows, int ld_part, int N,
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int rows, int row_first, int ld_part, int N,
                                                             const float* __restrict__ bias, int act, const float* __restrict__ R, int ldr,
                                                             int rcol0, float alpha, float* __restrict__ Y, int ldy, int ycol0) {
   const int n4 = (N + 3) / 4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows * n4; i += (long)gridDim.x * 256) {
-    const int row = (int)(i / n4), n = (int)(i % n4) * 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)(rows - row_first) * n4; i += (long)gridDim.x * 256) {
+    const int row = row_first + (int)(i / n4), n = (int)(i % n4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)row * ld_part + n);
     for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(partial + ((long)k * rows + row) * ld_part + n);
 #pragma unroll
@@ -763,11 +764,7 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = PREC_F32>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
-  if (a.compact) {
-    int tiles = 0;
-    for (int u = 0; u < a.n_utt; ++u) tiles += ceil_div(a.seg_host[u + 1] - a.seg_host[u], BN);
-    grid = dim3(npad / BM, tiles, a.ksplit > 1 ? a.ksplit : 1);
-  }
+  if (a.compact) grid = dim3(npad / BM, a.tiles_y, a.ksplit > 1 ? a.ksplit : 1);
   switch (epi) {
     case EPI_STORE: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR>), grid, block, st, e0, e1, a); break;
     case EPI_SPLIT_ACC: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL, PR>), grid, block, st, e0, e1, a); break;
@@ -789,107 +786,155 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     STTS_CHECK(a.seg[i].kc % 32 == 0 && a.seg[i].ldx % 4 == 0 && a.seg[i].xcol0 % 4 == 0, "conv_gemm: segment %d misaligned (kc %d ldx %d xcol0 %d)", i,
                a.seg[i].kc, a.seg[i].ldx, a.seg[i].xcol0);
   }
-  // Tile choice from tools/gemm_bench.py on MI355X (B = 8 x 960 rows): 128x128 with 8 waves once that fills the chip
-  // (>= 200 blocks), 128(cout) x 64(rows) with 4 waves for the mid-size layers, 128 x 32 for the small ones.
-  long blocks128 = (long)(npad / 128) * ceil_div(max_rows, 128) * n_utt;
-  if (a.seg_host) {
+  constexpr int kCUs = 256;
+  const int mt = npad / 128;
+  auto row_tiles = [&](int bn) -> long {  // exact when the host offsets are known (mixed lengths)
+    if (!a.seg_host) return (long)n_utt * ceil_div(max_rows, bn);
     long t = 0;
-    for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], 128);
-    blocks128 = (long)(npad / 128) * t;
-  }
+    for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], bn);
+    return t;
+  };
+  int iters = 0;
+  for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
+  const bool splittable = force_tile == 0 && epi == EPI_STORE && !a.sumsq_part;
+  // A launch takes about ceil(blocks / 256 CUs) block-times however many blocks are co-resident: a CU's matrix pipes are
+  // the shared resource (block-timeline trace, profiles/).  When the last round would be mostly empty (288 tiles = 1.125
+  // rounds for a 3.5 s batch of 8), the whole rounds run as they are and the REMAINDER row tiles run as a second launch
+  // with K cut over up to 8 blocks (+ reduce pass over those rows only): 1 + ~1/8 rounds instead of 2.
+  struct Plan {
+    long full_rt = 0, rem_rt = 0;  // row tiles in the plain launch / in the split-K remainder launch
+    int rem_ksp = 1;
+    double cost = 0;               // in 128-row block-times
+  };
+  auto plan_for = [&](int bn, double penalty) {
+    Plan p;
+    const long rt = row_tiles(bn), blocks = rt * mt;
+    const long whole = blocks / kCUs;
+    p.full_rt = rt;
+    p.cost = std::ceil((double)blocks / kCUs);
+    if (splittable && a.seg_host && whole >= 1 && blocks % kCUs != 0) {
+      const long full_rt = whole * kCUs / mt, rem_blocks = (rt - full_rt) * mt;
+      const int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, kCUs / std::max<long>(rem_blocks, 1)));
+      if (ksp >= 2 && full_rt > 0) {
+        const double hybrid = (double)(full_rt * mt) / kCUs + std::max((double)rem_blocks / kCUs, 1.0 / ksp) * 1.15 + 0.1;
+        if (hybrid < p.cost) {
+          p.full_rt = full_rt;
+          p.rem_rt = rt - full_rt;
+          p.rem_ksp = ksp;
+          p.cost = hybrid;
+        }
+      }
+    }
+    p.cost *= bn * penalty;
+    return p;
+  };
+  const long blocks128 = mt * row_tiles(128);
   int tile = force_tile;
   const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
+  Plan plan;
   if (tile == 0) {
     if (blocks128 < 24) tile = 3;
     else if (paired) tile = 2;
     else {
-      // 128x128 vs 128x64 by whole-chip rounds: a CU's matrix pipes are the shared resource, so the launch takes about
-      // ceil(blocks / 256 CUs) block-times however many blocks are co-resident.  288 blocks of 128x128 (a 3.5 s batch
-      // of 8) cost two rounds; 576 of 128x64 cost three half-sized ones.  (Block-timeline trace, profiles/.)
-      const int mt = npad / 128;
-      auto rounds_cost = [&](int bn, double penalty) {
-        double nb;
-        if (a.seg_host) {
-          long t = 0;
-          for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], bn);
-          nb = (double)mt * t;
-        } else {
-          nb = (double)mt * n_utt * ceil_div(max_rows, bn);
-        }
-        return std::ceil(nb / 256.0) * bn * penalty;
-      };
-      tile = rounds_cost(128, 1.0) <= rounds_cost(64, 1.03) ? 5 : 6;
+      // 128x128 vs 128x64 tiles by that cost (576 blocks of 128x64 cost three half-sized rounds)
+      const Plan p5 = plan_for(128, 1.0), p6 = plan_for(64, 1.03);
+      tile = p5.cost <= p6.cost ? 5 : 6;
+      plan = tile == 5 ? p5 : p6;
       // one 128x128 tile per CU (B = 8: every 512-channel layer): two K-groups of 8 waves share each staged tile, which
       // keeps the matrix pipes busier than 8 waves do (118 vs 125.5 us) and beats cutting K over two blocks plus the
       // reduce pass (131 us)
       // (fp32 only: with 16-bit operands the loop is staging-bound and 8 waves are faster, 34 vs 40 us)
-      if (tile == 5 && blocks128 <= 256 && a.prec == PREC_F32) tile = 8;
+      if (tile == 5 && blocks128 <= kCUs && a.prec == PREC_F32) tile = 8;
     }
+  }
+  const int bn = (tile == 5 || tile == 8 || tile == 11) ? 128 : (tile == 3 ? 32 : 64);
+  if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
+  if (tile == 8) {
+    plan.full_rt = row_tiles(bn);
+    plan.rem_rt = 0;
   }
   // (intra-block K-split, tiles 8-10, and 2-wave tiles measured no better than these at any layer shape: every
   //  configuration plateaus at ~80 % matrix-pipe occupancy)
+  GemmArgs as = a;
+  as.n_utt = n_utt;
+  as.compact = a.seg_host != nullptr;  // grid.y = the row tiles that exist; needed for tile ranges and for balanced XCDs
   // Block-level split-K for launches that cannot fill the chip (phoneme-rate layers, B = 1): one wave's MFMA chain over
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
-  GemmArgs as = a;
-  as.ksplit = 1;
-  as.n_utt = n_utt;
-  as.compact = a.seg_host != nullptr && (long)max_rows * n_utt != a.rows_total;  // mixed lengths: enumerate existing row tiles only
-  if (force_tile == 0 && epi == EPI_STORE && !a.sumsq_part && tile != 8) {
-    const int bn = tile == 5 ? 128 : (tile == 3 ? 32 : 64);
-    long blocks = (long)(npad / 128) * ceil_div(max_rows, bn) * n_utt;
-    if (as.compact) {
-      long t = 0;
-      for (int u = 0; u < n_utt; ++u) t += ceil_div(a.seg_host[u + 1] - a.seg_host[u], bn);
-      blocks = (long)(npad / 128) * t;
-    }
-    int iters = 0;
-    for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
+  int main_ksp = 1;
+  if (splittable && tile != 8 && plan.rem_rt == 0) {
+    const long blocks = plan.full_rt * mt;
     // (16-bit operands: a contraction that already has one tile per CU is shorter than the reduce pass it would add)
-    int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, (a.prec == PREC_F32 ? 512 : 255) / std::max<long>(blocks, 1)));
-    if (ksp >= 2) {
-      float* part = splitk_scratch(st, (size_t)ksp * a.rows_total * npad * sizeof(float));
-      if (part) {
-        as.ksplit = ksp;
-        as.partial = part;
-        as.ld_part = npad;
-      }
+    main_ksp = (int)std::min<long>(8, std::min<long>(iters / 4, (a.prec == PREC_F32 ? 512 : 255) / std::max<long>(blocks, 1)));
+    if (main_ksp < 2) main_ksp = 1;
+  }
+  float* part = nullptr;
+  if (main_ksp > 1 || plan.rem_rt > 0) {
+    part = splitk_scratch(st, (size_t)std::max(main_ksp, plan.rem_ksp) * a.rows_total * npad * sizeof(float));
+    if (!part) {  // no scratch: one plain launch
+      main_ksp = 1;
+      plan.full_rt += plan.rem_rt;
+      plan.rem_rt = 0;
     }
   }
-  GemmProfiler& prof = gemm_profiler();
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (prof.on) {
-    e0 = prof.next();
-    e1 = prof.next();
-  }
-  auto dispatch = [&](auto prec_tag) {
-    constexpr int PR = decltype(prec_tag)::value;
-    switch (tile) {
-      case 2: launch_cfg<128, 64, 2, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
-      case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
-      case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
-      case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
-      case 11:
-        if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves
-        break;
-      case 13:
-        if constexpr (PR == PREC_F32) launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 64-row tile
-        break;
-      default: launch_cfg<128, 32, 2, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
-    }
-  };
   if (a.prec != PREC_F32) {
     for (int i = 0; i < a.nseg; ++i) STTS_CHECK(a.seg[i].W16 != nullptr, "conv_gemm: 16-bit operand mode without 16-bit weights (segment %d)", i);
     STTS_CHECK(tile != 11 && tile != 13, "conv_gemm: LDS-DMA tiles are fp32 only");
   }
-  if (a.prec == PREC_BF16) dispatch(std::integral_constant<int, PREC_BF16>{});
-  else if (a.prec == PREC_F16) dispatch(std::integral_constant<int, PREC_F16>{});
-  else dispatch(std::integral_constant<int, PREC_F32>{});
-  if (as.ksplit > 1) {
-    const long work = (long)a.rows_total * ((a.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), 0, st, as.partial, as.ksplit,
-                       a.rows_total, as.ld_part, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha, a.Y, a.ldy, a.ycol0);
-  }
-  if (prof.on) prof.flops.push_back(gemm_algorithmic_flops(a));
+  GemmProfiler& prof = gemm_profiler();
+  const double flops = gemm_algorithmic_flops(a);
+  const long all_rt = plan.full_rt + plan.rem_rt;
+  auto launch_range = [&](long tile0, long ntiles, int ksp) {
+    as.tile0 = (int)tile0;
+    as.tiles_y = (int)ntiles;
+    as.ksplit = ksp;
+    as.partial = ksp > 1 ? part : nullptr;
+    as.ld_part = npad;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof.on) {
+      e0 = prof.next();
+      e1 = prof.next();
+      prof.flops.push_back(flops * (double)ntiles / (double)all_rt);
+    }
+    auto dispatch = [&](auto prec_tag) {
+      constexpr int PR = decltype(prec_tag)::value;
+      switch (tile) {
+        case 2: launch_cfg<128, 64, 2, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+        case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
+        case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
+        case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
+        case 11:
+          if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves
+          break;
+        case 13:
+          if constexpr (PR == PREC_F32) launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 64-row tile
+          break;
+        default: launch_cfg<128, 32, 2, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+      }
+    };
+    if (a.prec == PREC_BF16) dispatch(std::integral_constant<int, PREC_BF16>{});
+    else if (a.prec == PREC_F16) dispatch(std::integral_constant<int, PREC_F16>{});
+    else dispatch(std::integral_constant<int, PREC_F32>{});
+    if (ksp > 1) {
+      // first row of global row tile `tile0` (row tiles are numbered utterance by utterance, i.e. in row order)
+      int row_first = 0;
+      if (tile0 > 0) {
+        long t = tile0;
+        for (int u = 0; u < n_utt; ++u) {
+          const long tu = ceil_div(a.seg_host[u + 1] - a.seg_host[u], bn);
+          if (t < tu) {
+            row_first = a.seg_host[u] + (int)t * bn;
+            break;
+          }
+          t -= tu;
+        }
+      }
+      const long work = (long)(a.rows_total - row_first) * ((a.N + 3) / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), 0, st, part, ksp, a.rows_total,
+                         row_first, npad, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha, a.Y, a.ldy, a.ycol0);
+    }
+  };
+  if (plan.full_rt > 0) launch_range(0, plan.full_rt, main_ksp);
+  if (plan.rem_rt > 0) launch_range(plan.full_rt, plan.rem_rt, plan.rem_ksp);
   STTS_HIP(hipGetLastError());
   return 0;
 }
