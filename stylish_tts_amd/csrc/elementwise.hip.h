@@ -87,6 +87,45 @@ __global__ void __launch_bounds__(256) adain_partial_kernel(const float* __restr
   }
 }
 
+// merge of the chunk statistics of channel c of utterance u (len rows) with the style affine:
+//   (1 + gamma) * (x - mean) * rstd + beta = x * scale + shift
+__device__ __forceinline__ void adain_scale_shift(const float* __restrict__ part, int ldp, int nchunk, int u, int c, int len,
+                                                  const float* __restrict__ gb, int ld_gb, int gcol0, int C, float eps, float* scale, float* shift) {
+  const float n = (float)len;
+  const int nch = (len + kStatChunk - 1) / kStatChunk;
+  float mean = 0.f;
+  for (int ch = 0; ch < nch; ++ch) {
+    const float nc = (float)min(kStatChunk, len - ch * kStatChunk);
+    mean += nc * part[((long)(u * nchunk + ch) * 2) * ldp + c];
+  }
+  mean /= n;
+  float m2 = 0.f;
+  for (int ch = 0; ch < nch; ++ch) {
+    const float nc = (float)min(kStatChunk, len - ch * kStatChunk);
+    const float* p = part + ((long)(u * nchunk + ch) * 2) * ldp;
+    const float d = p[c] - mean;
+    m2 += p[ldp + c] + nc * d * d;
+  }
+  const float rstd = rsqrtf(m2 / n + eps);
+  const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
+  *scale = rstd * (1.0f + g);
+  *shift = be - mean * (*scale);
+}
+
+// AdaIN as an input affine of the following contraction (conv_gemm_f32<..., XAFF>): aff[u][0][c] = scale, aff[u][1][c] =
+// shift for c < C, zeros in the pad columns (so pad columns of X contribute nothing whatever they hold).
+// grid (ceil(ld_aff / 64), n_utt), block 64.
+__global__ void __launch_bounds__(64) adain_affine_kernel(const float* __restrict__ part, int ldp, int nchunk, const int* __restrict__ seg_off,
+                                                          const float* __restrict__ gb, int ld_gb, int gcol0, int C, float eps,
+                                                          float* __restrict__ aff, int ld_aff) {
+  const int u = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= ld_aff) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < C) adain_scale_shift(part, ldp, nchunk, u, c, seg_off[u + 1] - seg_off[u], gb, ld_gb, gcol0, C, eps, &sc, &sh);
+  aff[((long)u * 2) * ld_aff + c] = sc;
+  aff[((long)u * 2 + 1) * ld_aff + c] = sh;
+}
+
 // grid (ceil(ldy/64), row blocks of 64, n_utt); block 256 = 16 float4 columns x 16 row lanes.
 // snake: y = v + sin^2(alpha*v)/alpha (AdaptiveGeneratorBlock, models/ada_norm.py:114,117) when alpha != null.
 __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int C,
@@ -99,29 +138,11 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
   if (r0 >= hi) return;
   // the block's 64 channels: one thread per channel merges the chunk statistics, result shared through LDS
   __shared__ float s_sc[64], s_sh[64], s_al[64];
-  const float n = (float)(hi - lo);
-  const int nch = (hi - lo + kStatChunk - 1) / kStatChunk;
   if (threadIdx.x < 64) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     float scv = 0.f, shv = 0.f, alv = 1.f;
     if (c < C) {
-      float mean = 0.f;
-      for (int ch = 0; ch < nch; ++ch) {
-        const float nc = (float)min(kStatChunk, hi - lo - ch * kStatChunk);
-        mean += nc * part[((long)(u * nchunk + ch) * 2) * ldp + c];
-      }
-      mean /= n;
-      float m2 = 0.f;
-      for (int ch = 0; ch < nch; ++ch) {
-        const float nc = (float)min(kStatChunk, hi - lo - ch * kStatChunk);
-        const float* p = part + ((long)(u * nchunk + ch) * 2) * ldp;
-        const float d = p[c] - mean;
-        m2 += p[ldp + c] + nc * d * d;
-      }
-      const float rstd = rsqrtf(m2 / n + eps);
-      const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
-      scv = rstd * (1.0f + g);
-      shv = be - mean * scv;
+      adain_scale_shift(part, ldp, nchunk, u, c, hi - lo, gb, ld_gb, gcol0, C, eps, &scv, &shv);
       if (alpha) alv = alpha[c];
     }
     s_sc[threadIdx.x] = scv;

@@ -64,6 +64,9 @@ struct GemmArgs {
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
   int prec;               // PREC_F32 / PREC_BF16 / PREC_F16 operands (every segment then carries W16)
+  // input affine of segment 0 (AdaIN folded into the staging): x' = lrelu_0.2(x * xaff[u][0][c] + xaff[u][1][c]); EPI_STORE only
+  const float* xaff;
+  int ld_xaff;
   long long* dbg;         // block-timeline records (only written when built with -DSTTS_GEMM_TRACE; tools/gemm_bench.py)
   const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
   int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
@@ -140,8 +143,9 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4 a, const f32x4 b, const f32
 // KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
 // partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
 // have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, bool XAFF = false>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
+  static_assert(!(XAFF && GLDS), "the input affine lives on the register staging path");
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
   constexpr bool B16 = PREC != PREC_F32;
   static_assert(!(B16 && GLDS), "16-bit operands use the register staging path");
@@ -248,6 +252,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   struct RegSet {
     f32x4 x[XL], w[WL];
     bool ok[XL];  // rows outside the utterance are zeroed when the registers are consumed (lstore), so the load stays in flight
+    f32x4 sc, sh;  // XAFF: scale / shift of this thread's 4 channels (segment 0), identity elsewhere
+    bool aff;
   };
   RegSet rsA, rsB;
   // Addressing: uniform (scalar) base pointers + 32-bit per-thread byte offsets, so the loads use the saddr form and the
@@ -283,6 +289,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) rs.w[i] = *reinterpret_cast<const f32x4*>(wb + woff[i]);
+    if constexpr (XAFF) {
+      rs.aff = s == 0;
+      const float* ap = a.xaff + (long)utt * 2 * a.ld_xaff + (rs.aff ? chunk * 32 + (tid & 7) * 4 : 0);
+      rs.sc = *reinterpret_cast<const f32x4*>(ap);
+      rs.sh = *reinterpret_cast<const f32x4*>(ap + a.ld_xaff);
+    }
     // advance: TAP is the inner index, so the taps of one 32-channel chunk re-read (almost) the same rows of X
     // back to back and hit L1/L2; channel-inner order re-streamed the whole X tile per tap from the fabric (rocprof
     // FETCH_SIZE was ~10x the compulsory bytes).  Scalar selects only; the last tile is re-loaded when the cursor
@@ -302,6 +314,21 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       seg_offsets();
     }
   };
+  auto xin = [&](const RegSet& rs, int i) {  // the value of X load i that enters LDS
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v = rs.x[i];
+    if constexpr (XAFF) {
+      f32x4 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // scale 0 marks a pad column: its X value may be uninitialised memory (NaN * 0 would poison the tile)
+        const float y = (rs.sc[q] == 0.0f ? 0.0f : v[q] * rs.sc[q]) + rs.sh[q];
+        t[q] = y >= 0.0f ? y : 0.2f * y;
+      }
+      v = rs.aff ? t : v;
+    }
+    return rs.ok[i] ? v : z;
+  };
   auto lstore = [&](const RegSet& rs, int b) {
     if constexpr (B16) {
       f32x4* Xs = lds + b * (BN + BM) * 4;  // 4 x 16-byte slots (64 bytes) per row
@@ -312,7 +339,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         const int idx = tid + i * NT;
         const int r = idx >> 3, sl = idx & 7;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        Xh[(r * 4 + ((sl >> 1) ^ ((r >> 2) & 3))) * 2 + (sl & 1)] = pack4_16<PREC>(rs.ok[i] ? rs.x[i] : z);
+        Xh[(r * 4 + ((sl >> 1) ^ ((r >> 2) & 3))) * 2 + (sl & 1)] = pack4_16<PREC>(xin(rs, i));
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
@@ -328,7 +355,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       const int idx = tid + i * NT;
       const int r = idx >> 3, sl = idx & 7;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = rs.ok[i] ? rs.x[i] : z;
+      Xs[r * 8 + (sl ^ ((r >> 1) & 7))] = xin(rs, i);
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
@@ -766,7 +793,15 @@ inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
   if (a.compact) grid = dim3(npad / BM, a.tiles_y, a.ksplit > 1 ? a.ksplit : 1);
   switch (epi) {
-    case EPI_STORE: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR>), grid, block, st, e0, e1, a); break;
+    case EPI_STORE:
+      if constexpr (!GL) {
+        if (a.xaff) {
+          STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true>), grid, block, st, e0, e1, a);
+          break;
+        }
+      }
+      STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR>), grid, block, st, e0, e1, a);
+      break;
     case EPI_SPLIT_ACC: STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_SPLIT_ACC, KS, GL, PR>), grid, block, st, e0, e1, a); break;
     default:
       if constexpr (BM / WM >= 64) {
