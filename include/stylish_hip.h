@@ -186,8 +186,8 @@ int stts_op_mrf_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt
                       int ldy, void* ws, size_t ws_bytes);
 
 /* Tuning aid (tools/gemm_bench.py): average time of `iters` back-to-back contraction launches on synthetic data.
- * tile: 0 = the launcher's own choice; tune bits: 2/4/8/16 ablations (results invalid), 64 block-timeline trace
- * (only when built with -DSTTS_GEMM_TRACE), 128 bf16 operands, 256 fp16 operands. */
+ * tile: 0 = the launcher's own choice; tune bits: 128 bf16 operands, 256 fp16 operands; only in a library built with
+ * -DSTTS_GEMM_TRACE: 2/4/8/16 K-loop ablations (results invalid, timing only), 64 block-timeline trace. */
 int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int cin, int cout, int k, int tile, int iters, double* avg_ms, int tune);
 
 #ifdef __cplusplus

@@ -219,9 +219,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   const long long dbg_c0 = clock64();
   if (a.dbg && tid == 0) { a.dbg[8 * (long)dbg_blk + 5] = __builtin_amdgcn_s_getreg(0xF804); a.dbg[8 * (long)dbg_blk + 6] = __builtin_amdgcn_s_getreg(0xF814); }
   auto stamp_end = [&]() { stamp(3); if (a.dbg && tid == 0) a.dbg[8 * (long)dbg_blk + 7] = clock64() - dbg_c0; };
+  auto ablate = [&](int bit) { return (a.tune & bit) != 0; };  // timing-only ablations of the K loop (tools/gemm_bench.py)
 #else
   auto stamp = [&](int) {};
   auto stamp_end = [&]() {};
+  auto ablate = [](int) { return false; };
 #endif
   stamp(0);
   const int kg = (tid >> 6) / (WARPS_M * WARPS_N), wid = (tid >> 6) % (WARPS_M * WARPS_N);  // K-group, wave position
@@ -273,7 +275,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   seg_offsets();
   auto gload = [&](RegSet& rs) {
     const int shift = (tap - g_pad) * g_dil;
+#ifdef STTS_GEMM_TRACE
     const bool hot = a.tune & 16;  // ablation only: every tile read hits the same few KB (L1/L2 resident) -> wrong results
+#else
+    constexpr bool hot = false;
+#endif
     const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + (hot ? 0 : chunk * 32));
     const char* wb = B16 ? reinterpret_cast<const char*>(gW16 + tap * g_kc + chunk * 32)
                          : reinterpret_cast<const char*>((hot ? a.seg[0].W : gW) + (hot ? 0 : tap * g_kc + chunk * 32));
@@ -529,9 +535,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       }
     } else if constexpr (KSPLIT == 1) {
       mma_step(Xs, Ws, 0);
-      if (!(a.tune & 4)) lstore(nset, (it + 1) & 1);
+      if (!ablate(4)) lstore(nset, (it + 1) & 1);
       mma_step(Xs, Ws, 1);
-      if (!(a.tune & 8)) gload(nset);
+      if (!ablate(8)) gload(nset);
       mma_step(Xs, Ws, 2);
       mma_step(Xs, Ws, 3);
     } else {
@@ -540,7 +546,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       gload(nset);
       mma_step(Xs, Ws, 2 * kg + 1);
     }
-    if (!(a.tune & 2)) __syncthreads();
+    if (!ablate(2)) __syncthreads();
   };
   for (int it = 0; it < total; it += 2) {
     iter(it, rsB);
