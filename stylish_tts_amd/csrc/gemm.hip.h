@@ -143,7 +143,7 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4 a, const f32x4 b, const f32
 // KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
 // partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
 // have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, bool XAFF = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, bool XAFF = false, bool MSEG = true>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
   static_assert(!(XAFF && GLDS), "the input affine lives on the register staging path");
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
@@ -307,17 +307,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     // would run off the end.
     const bool wrapt1 = tap + 1 >= g_ntaps;
     const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);  // segment finished
-    const bool last = wrapt && (s + 1 >= nseg);
+    const bool last = wrapt && (!MSEG || s + 1 >= nseg);
     tap = last ? tap : (wrapt1 ? 0 : tap + 1);
     chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
-    if (wrapt && !last) {  // uniform, taken at most twice per kernel
-      ++s;
-      const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
-      gX = n.X + n.xcol0;
-      gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
-      if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
-      g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
-      seg_offsets();
+    if constexpr (MSEG) {  // (single-segment launches are compiled without this branch: the K loop is one basic block)
+      if (wrapt && !last) {  // uniform, taken at most twice per kernel
+        ++s;
+        const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
+        gX = n.X + n.xcol0;
+        gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+        if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+        g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+        seg_offsets();
+      }
     }
   };
   auto xin = [&](const RegSet& rs, int i) {  // the value of X load i that enters LDS
@@ -548,9 +550,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     }
     if (!ablate(2)) __syncthreads();
   };
-  for (int it = 0; it < total; it += 2) {
-    iter(it, rsB);
-    if (it + 1 < total) iter(it + 1, rsA);
+  {
+    int it = 0;
+    for (; it + 1 < total; it += 2) {  // branch-free body: two iterations, one per register set
+      iter(it, rsB);
+      iter(it + 1, rsA);
+    }
+    if (it < total) iter(it, rsB);
   }
   stamp(2);
 #ifdef STTS_GEMM_TRACE
@@ -802,7 +808,12 @@ inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int
     case EPI_STORE:
       if constexpr (!GL) {
         if (a.xaff) {
-          STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true>), grid, block, st, e0, e1, a);
+          if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true, false>), grid, block, st, e0, e1, a);
+          else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true, true>), grid, block, st, e0, e1, a);
+          break;
+        }
+        if (a.nseg == 1) {
+          STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, false, false>), grid, block, st, e0, e1, a);
           break;
         }
       }
