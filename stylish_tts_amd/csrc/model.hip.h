@@ -14,6 +14,7 @@
 #include "signal.hip.h"
 #include "phoneme.hip.h"
 #include "wn_layer.hip.h"
+#include "wn_layer_small.hip.h"
 
 namespace stts {
 
@@ -701,7 +702,9 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh) + extra);
       }
       const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
-      if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_BF16>, wgrid, dim3(1024), st, e0, e1, w);
+      // small batches (fp32): 16-row blocks, twice the workgroups at half the chain length (wn_layer_small.hip.h)
+      if (c->prec == PREC_F32 && R <= 4096) STTS_LAUNCH_TIMED(wn_layer_rows16_kernel, dim3(ceil_div(ml, 16), s.n_utt), dim3(1024), st, e0, e1, w);
+      else if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_BF16>, wgrid, dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_F16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F16>, wgrid, dim3(1024), st, e0, e1, w);
       else STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F32>, wgrid, dim3(1024), st, e0, e1, w);
       std::swap(hcur, hnext);
