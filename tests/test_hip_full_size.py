@@ -92,3 +92,26 @@ def test_batch_scope_changes_only_the_harmonic_count(hip):
     lengths = [320, 480]
     x = make_inputs(lengths, "full.scope")
     assert torch.equal(run(hip, lengths, x, batch_scope=True), run(hip, lengths, x, batch_scope=False))
+
+
+@pytest.mark.parametrize("prec,lengths,tag,tol", [("bf16", [960] * 64, "full.cfg3", 1.2e-2), ("f16", [3200] * 16, "full.cfg5h", 1.5e-3)])
+def test_cfg3_cfg5_16bit_shapes(cfg, weights, hip, prec, lengths, tag, tol):
+    """cfg3 (B = 64 x 3 s, bf16 operands) and cfg5 (10 s segments, fp16 operands; 16 of the 64 per GPU): deterministic,
+    finite, batch == per-utterance, and within the mode's stated tolerance of the fp32 engine on the same inputs."""
+    from stylish_tts_amd.runtime import HipModel
+
+    m = HipModel(cfg, 0, precision=prec)
+    m.load_weights({"speech_predictor": weights["speech_predictor"]}, which=7)
+    x = make_inputs(lengths, tag)
+    a = run(m, lengths, x)
+    assert torch.equal(a, run(m, lengths, x))
+    assert bool(torch.isfinite(a).all()) and float(a.abs().max()) <= 1.0
+    L = lengths[0]
+    for u in (0, len(lengths) - 1):
+        one = run(m, [L], slice_inputs(x, L * u, L * (u + 1), u))
+        # (tile shapes differ between the batch and the single run: a different fp32 summation order can flip individual
+        #  16-bit operand roundings, so this is the mode's tolerance, not the fp32 one)
+        assert float((one - a[75 * L * u : 75 * L * (u + 1)]).abs().max()) < tol
+    ref = run(hip, lengths[:4], slice_inputs(x, 0, 4 * L, 0) | dict(style=x["style"][:4].contiguous()))
+    assert float((ref - a[: 75 * 4 * L]).abs().max()) < tol
+    m.close()
