@@ -199,9 +199,21 @@ struct LnOut {
   const float* b;  // static beta (ignored when adaptive)
   int ld_g, gcol0;
 };
+// LnIn (optional): the row is not read from X but finished from the partial sums of a split-K contraction,
+//   x = (act(sum_k partial[k][row] + bias) [+ R[row]]) * alpha  in slice order (what splitk_reduce_kernel computes),
+// so a contraction followed by a LayerNorm needs no separate reduce pass.
+struct LnIn {
+  const float* partial;  // null: read X
+  int ksplit, slice_rows, ld_part;
+  const float* bias;
+  int act;
+  const float* R;
+  int ldr, rcol0;
+  float alpha;
+};
 __global__ void __launch_bounds__(256) row_layernorm_kernel(const float* __restrict__ X, int ldx, int C, int n_rows,
                                                             const int* __restrict__ row_utt, float eps, int adaptive, int nout,
-                                                            LnOut o0, LnOut o1, int act) {
+                                                            LnOut o0, LnOut o1, int act, LnIn in) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
@@ -212,7 +224,23 @@ __global__ void __launch_bounds__(256) row_layernorm_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int q = lane + i * 64;
-    v[i] = q < nv ? *reinterpret_cast<const float4*>(x + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nv) {
+      if (in.partial) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(in.partial + (long)row * in.ld_part + q * 4);
+        for (int k = 1; k < in.ksplit; ++k) t += *reinterpret_cast<const f32x4*>(in.partial + ((long)k * in.slice_rows + row) * in.ld_part + q * 4);
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          e[c] = act_apply(t[c] + (in.bias ? in.bias[q * 4 + c] : 0.0f), in.act);
+          if (in.R) e[c] += in.R[(long)row * in.ldr + in.rcol0 + q * 4 + c];
+          e[c] *= in.alpha;
+        }
+        v[i] = make_float4(e[0], e[1], e[2], e[3]);
+      } else {
+        v[i] = *reinterpret_cast<const float4*>(x + q * 4);
+      }
+    }
     s += v[i].x + v[i].y + v[i].z + v[i].w;
   }
   const float mean = wave_sum(s) / (float)C;

@@ -53,6 +53,13 @@ struct GemmSeg {
   int kreal;  // un-padded input channels (host side: algorithmic FLOP accounting only)
 };
 
+// Filled by the launcher when the caller takes over the split-K reduction (GemmArgs::defer): ksplit == 1 means the
+// contraction wrote Y itself.
+struct SplitInfo {
+  const float* partial;
+  int ksplit, slice_rows, ld_part;
+};
+
 struct GemmArgs {
   GemmSeg seg[3];
   int nseg;
@@ -72,6 +79,7 @@ struct GemmArgs {
   int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
   float* partial;         // [ksplit][rows_total][ld_part] raw partial sums (EPI_STORE only; splitk_reduce_kernel finishes)
   int ld_part;
+  SplitInfo* defer;       // host side: non-null = do not launch the reduce pass, report the partials instead (e.g. to a LayerNorm)
   int N;               // output channels actually stored (paired epilogues: channels of the result)
   const float* bias;   // [Npad] in packed row order, may be null
   // EPI_STORE
@@ -966,7 +974,9 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     if (a.prec == PREC_BF16) dispatch(std::integral_constant<int, PREC_BF16>{});
     else if (a.prec == PREC_F16) dispatch(std::integral_constant<int, PREC_F16>{});
     else dispatch(std::integral_constant<int, PREC_F32>{});
-    if (ksp > 1) {
+    if (ksp > 1 && a.defer && tile0 == 0 && ntiles == all_rt) {
+      *a.defer = SplitInfo{part, ksp, a.rows_total, npad};
+    } else if (ksp > 1) {
       // first row of global row tile `tile0` (row tiles are numbered utterance by utterance, i.e. in row order)
       int row_first = 0;
       if (tile0 > 0) {
@@ -985,6 +995,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
                          row_first, npad, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha, a.Y, a.ldy, a.ycol0);
     }
   };
+  if (a.defer) *a.defer = SplitInfo{nullptr, 1, 0, 0};
   if (plan.full_rt > 0) launch_range(0, plan.full_rt, main_ksp);
   if (plan.rem_rt > 0) launch_range(plan.full_rt, plan.rem_rt, plan.rem_ksp);
   STTS_HIP(hipGetLastError());

@@ -744,9 +744,9 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
 // stage: vocoder body + iSTFT (models/generator.py:412-433)
 // ------------------------------------------------------------------------------------------------
 inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows, const int* row_utt, float eps, int adaptive, int nout,
-                     const LnOut& o0, const LnOut& o1, int act) {
+                     const LnOut& o0, const LnOut& o1, int act, const LnIn& in = LnIn{}) {
   hipLaunchKernelGGL(row_layernorm_kernel, dim3((unsigned)ceil_div((int)n_rows, 4)), dim3(256), 0, st, X, ldx, C, (int)n_rows, row_utt, eps,
-                     adaptive, nout, o0, o1, act);
+                     adaptive, nout, o0, o1, act, in);
   STTS_HIP(hipGetLastError());
   return 0;
 }

@@ -28,20 +28,24 @@ __global__ void __launch_bounds__(256) embed_kernel(const long* __restrict__ tok
 //   j <  d/2: x_j' = x_j cos(p th_j) - x_{j+d/2} sin(p th_j)
 //   j >= d/2: x_j' = x_j cos(p th_{j-d/2}) + x_{j-d/2} sin(p th_{j-d/2}),   th_i = 10000^(-2i/d), p = position in the utterance
 // grid (row chunks, n_utt); thread per (row, head, pair).
-__global__ void __launch_bounds__(256) rope_kernel(float* __restrict__ X, int ldx, int col0, int n_heads, int kc, int d,
+// col1 >= 0: the same rotation also on the column block at col1 (queries and keys of a fused q|k|v buffer in one launch).
+__global__ void __launch_bounds__(256) rope_kernel(float* __restrict__ X, int ldx, int col0, int col1, int n_heads, int kc, int d,
                                                    const int* __restrict__ seg_off) {
   const int u = blockIdx.y;
   const int lo = seg_off[u], n = seg_off[u + 1] - lo;
   const int half = d / 2;
-  const long total = (long)n * n_heads * half;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const long per = (long)n * n_heads * half;
+  const long total = col1 >= 0 ? 2 * per : per;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += (long)gridDim.x * 256) {
+    const long i = i0 >= per ? i0 - per : i0;
+    const int cbase = i0 >= per ? col1 : col0;
     const int j = (int)(i % half);
     const int h = (int)((i / half) % n_heads);
     const int p = (int)(i / ((long)half * n_heads));
     const float theta = 1.0f / powf(10000.0f, (float)(2 * j) / (float)d);
     const float ang = (float)p * theta;
     const float cs = cosf(ang), sn = sinf(ang);
-    float* x = X + (long)(lo + p) * ldx + col0 + h * kc;
+    float* x = X + (long)(lo + p) * ldx + cbase + h * kc;
     const float a = x[j], b = x[j + half];
     x[j] = a * cs - b * sn;
     x[j + half] = b * cs + a * sn;

@@ -257,6 +257,22 @@ inline int adaptive_ln(hipStream_t st, const float* X, int ldx, int C, long rows
   return ln_launch(st, X, ldx, C, rows, row_utt, eps, 1, 1, o0, o1, ACT_NONE);
 }
 
+// Conv/Linear (+ residual) followed by a LayerNorm over the channels.  When the launcher cut K over several blocks the
+// LayerNorm kernel finishes the partial sums itself (one launch less); otherwise it reads the contraction's output t.
+inline int gemm_ln(hipStream_t st, const Seg& s, const float* X, int ldx, const PackedConv& w, float* t, int ldt, const float* R, int ldr, int C,
+                   float eps, int adaptive, const int* row_utt, const LnOut& o0, int act_ln) {
+  GemmArgs a = gemm_args(s);
+  set_seg(a, 0, X, ldx, 0, w);
+  a.N = w.N; a.bias = w.bias; a.Y = t; a.ldy = ldt; a.R = R; a.ldr = ldr;
+  SplitInfo info{};
+  a.defer = &info;
+  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, w.npad, s.n_utt, s.max_len()));
+  LnIn in{};
+  if (info.ksplit > 1) in = LnIn{info.partial, info.ksplit, info.slice_rows, info.ld_part, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha};
+  LnOut o1{};
+  return ln_launch(st, t, ldt, C, s.rows(), row_utt, eps, adaptive, 1, o0, o1, act_ln, in);
+}
+
 inline int run_attention(hipStream_t st, const Seg& sq, const Seg& sk, const float* Q, int ldq, int qcol0, const float* K, int ldk, int kcol0,
                          const float* V, int ldv, int vcol0, float* O, int ldo, int heads, int kc, const int* band_centre, int window) {
   STTS_CHECK(kc <= kAttnMaxKc && kc % 4 == 0, "attention: head size %d unsupported", kc);
@@ -266,10 +282,10 @@ inline int run_attention(hipStream_t st, const Seg& sq, const Seg& sk, const flo
   STTS_HIP(hipGetLastError());
   return 0;
 }
-inline void run_rope(hipStream_t st, const Seg& s, float* X, int ldx, int col0, int heads, int kc) {
+inline void run_rope(hipStream_t st, const Seg& s, float* X, int ldx, int col0, int heads, int kc, int col1 = -1) {
   const int d = (int)(kc * 0.5);
-  hipLaunchKernelGGL(rope_kernel, dim3(std::max(1, ceil_div(s.max_len() * heads * (d / 2), 256)), s.n_utt), dim3(256), 0, st, X, ldx, col0, heads, kc, d,
-                     s.dev);
+  hipLaunchKernelGGL(rope_kernel, dim3(std::max(1, ceil_div(s.max_len() * heads * (d / 2) * (col1 >= 0 ? 2 : 1), 256)), s.n_utt), dim3(256), 0, st, X,
+                     ldx, col0, col1, heads, kc, d, s.dev);
 }
 
 // ------------------------------------------------------------------------------------------------ TextEncoder.forward
@@ -290,8 +306,7 @@ inline int text_encoder_forward(stts_ctx* c, hipStream_t st, const TextEncW& W, 
   // ConvReluNorm prenet (text_encoder.py:79-86): 3 x (conv k5 -> channel LayerNorm eps 1e-4 -> ReLU), + 1x1 proj residual
   const float* cur = x;
   for (int i = 0; i < 3; ++i) {
-    STTS_TRY(gemm_store(st, s, cur, C, 0, W.pre[i], t, C, 0));
-    STTS_TRY(static_ln(st, t, C, C, R, 1e-4f, W.pre_g[i], W.pre_b[i], h, C, ACT_RELU));
+    STTS_TRY(gemm_ln(st, s, cur, C, W.pre[i], t, C, nullptr, 0, C, 1e-4f, 0, nullptr, LnOut{h, C, 0, W.pre_g[i], W.pre_b[i], 0, 0}, ACT_RELU));
     cur = h;
   }
   STTS_TRY(gemm_store(st, s, h, C, 0, W.pre_proj, t, C, 0, ACT_NONE, x, C));
@@ -300,14 +315,11 @@ inline int text_encoder_forward(stts_ctx* c, hipStream_t st, const TextEncW& W, 
   for (int i = 0; i < W.n_layers; ++i) {
     const TextEncW::Layer& L = W.layer[i];
     STTS_TRY(gemm_store(st, s, x, C, 0, L.qkv, qkv, 3 * C, 0));
-    run_rope(st, s, qkv, 3 * C, 0, W.heads, kc);
-    run_rope(st, s, qkv, 3 * C, C, W.heads, kc);
+    run_rope(st, s, qkv, 3 * C, 0, W.heads, kc, C);  // q and k blocks of the fused q|k|v buffer
     STTS_TRY(run_attention(st, s, s, qkv, 3 * C, 0, qkv, 3 * C, C, qkv, 3 * C, 2 * C, att, C, W.heads, kc, nullptr, 0));
-    STTS_TRY(gemm_store(st, s, att, C, 0, L.o, t, C, 0, ACT_NONE, x, C));
-    STTS_TRY(static_ln(st, t, C, C, R, 1e-4f, L.g1, L.b1, x, C, ACT_NONE));
+    STTS_TRY(gemm_ln(st, s, att, C, L.o, t, C, x, C, C, 1e-4f, 0, nullptr, LnOut{x, C, 0, L.g1, L.b1, 0, 0}, ACT_NONE));
     STTS_TRY(gemm_store(st, s, x, C, 0, L.f1, ff, W.filter, 0, ACT_RELU));
-    STTS_TRY(gemm_store(st, s, ff, W.filter, 0, L.f2, t, C, 0, ACT_NONE, x, C));
-    STTS_TRY(static_ln(st, t, C, C, R, 1e-4f, L.g2, L.b2, x, C, ACT_NONE));
+    STTS_TRY(gemm_ln(st, s, ff, W.filter, L.f2, t, C, x, C, C, 1e-4f, 0, nullptr, LnOut{x, C, 0, L.g2, L.b2, 0, 0}, ACT_NONE));
   }
   if (x_out) STTS_HIP(hipMemcpyAsync(x_out, x, R * C * sizeof(float), hipMemcpyDeviceToDevice, st));
   STTS_TRY(gemm_store(st, s, x, C, 0, W.proj_m, mu, ld_mu, 0));
@@ -376,14 +388,11 @@ inline int prosody_forward(hipStream_t st, const ProsodyW& W, const Seg& s, cons
   for (int i = 0; i < W.n_layers; ++i) {
     const ProsodyW::L& L = W.l[i];
     STTS_TRY(gemm_store(st, s, x, C, 0, L.qkv, qkv, 3 * C, 0));
-    run_rope(st, s, qkv, 3 * C, 0, W.heads, kc);
-    run_rope(st, s, qkv, 3 * C, C, W.heads, kc);
+    run_rope(st, s, qkv, 3 * C, 0, W.heads, kc, C);  // q and k blocks of the fused q|k|v buffer
     STTS_TRY(run_attention(st, s, s, qkv, 3 * C, 0, qkv, 3 * C, C, qkv, 3 * C, 2 * C, att, C, W.heads, kc, nullptr, 0));
-    STTS_TRY(gemm_store(st, s, att, C, 0, L.o, t, C, 0, ACT_NONE, x, C));
-    STTS_TRY(adaptive_ln(st, t, C, C, R, row_utt, 1e-5f, sty, ld_sty, L.n1.col0, y, C));
+    STTS_TRY(gemm_ln(st, s, att, C, L.o, t, C, x, C, C, 1e-5f, 1, row_utt, LnOut{y, C, 0, sty, nullptr, ld_sty, L.n1.col0}, ACT_NONE));
     STTS_TRY(gemm_store(st, s, y, C, 0, L.f1, ff, 2 * C, 0, ACT_RELU));
-    STTS_TRY(gemm_store(st, s, ff, 2 * C, 0, L.f2, t, C, 0, ACT_NONE, y, C));
-    STTS_TRY(adaptive_ln(st, t, C, C, R, row_utt, 1e-5f, sty, ld_sty, L.n2.col0, y, C));
+    STTS_TRY(gemm_ln(st, s, ff, 2 * C, L.f2, t, C, y, C, C, 1e-5f, 1, row_utt, LnOut{y, C, 0, sty, nullptr, ld_sty, L.n2.col0}, ACT_NONE));
     STTS_TRY(gemm_store(st, s, y, C, 0, L.proj, x, C, 0));  // columns [0,d); the style columns of x persist
   }
   return 0;
