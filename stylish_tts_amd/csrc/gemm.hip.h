@@ -893,7 +893,9 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
   Plan plan;
   if (tile == 0) {
-    if (blocks128 < 24) tile = 3;
+    // small launches: 32-row tiles; unpaired epilogues spread the 128 output channels over four waves (a wave's MFMA
+    // chain per iteration is then 16 instead of 32 instructions: these launches are latency-bound on that chain)
+    if (blocks128 < 24) tile = paired ? 3 : 4;
     else if (paired) tile = 2;
     else {
       // 128x128 vs 128x64 tiles by that cost (576 blocks of 128x64 cost three half-sized rounds)
@@ -907,7 +909,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       if (tile == 5 && blocks128 <= kCUs && a.prec == PREC_F32) tile = 8;
     }
   }
-  const int bn = (tile == 5 || tile == 8 || tile == 11) ? 128 : (tile == 3 ? 32 : 64);
+  const int bn = (tile == 5 || tile == 8 || tile == 11) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
   if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
   if (tile == 8) {
     plan.full_rt = row_tiles(bn);
@@ -959,6 +961,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       constexpr int PR = decltype(prec_tag)::value;
       switch (tile) {
         case 2: launch_cfg<128, 64, 2, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+        case 4: launch_cfg<128, 32, 4, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 32-row tile, 4 waves of one 32x32 tile each
         case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
         case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
         case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
