@@ -93,6 +93,14 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME, libamdhip64.so.7, as
+    # the system one this library is linked against).  If this library were loaded first the system copy would come in,
+    # torch would then add its own, and whichever initialises second reports "no ROCm-capable device".  Importing torch
+    # first makes the dynamic loader resolve our dependency to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure C-ABI use without PyTorch: the system runtime is the only one
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
