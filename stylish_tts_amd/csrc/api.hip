@@ -354,9 +354,22 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   HostTensor b;
   b.shape = {cout};
   if (bias_host) b.data.assign(bias_host, bias_host + cout);
+  Seg s{n_utt, seg_off_host, seg_off_dev};
+  if (force_tile == -4) {  // the Winograd F(4, k) form (k = 3 or 7, dilation 1): winograd.hip.h
+    STTS_CHECK(dil == 1 && precision == 0, "op_conv1d: the Winograd form is fp32, dilation 1");
+    WinoConv wc;
+    STTS_TRY(pack_winograd(&tmp, w, bias_host ? &b : nullptr, 0, cin, cout, &wc));
+    float* scratch = nullptr;
+    STTS_HIP(hipMalloc(&scratch, wino_scratch_floats(s, wc) * sizeof(float)));
+    tmp.allocs.push_back(scratch);
+    int r = run_winograd(st, s, x, ldx, wc, y, ldy, act, nullptr, 0, 1.0f, scratch);
+    hipError_t e = hipStreamSynchronize(st);
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    STTS_HIP(e);
+    return r;
+  }
   PackedConv pc;
   STTS_TRY(pack_rows(&tmp, w, bias_host ? &b : nullptr, plain_rows(cout), 0, cin, round_up(cin, 32), cout, &pc));
-  Seg s{n_utt, seg_off_host, seg_off_dev};
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, x, ldx, 0, pc, (k - 1) / 2, dil);
   a.N = cout; a.bias = pc.bias; a.Y = y; a.ldy = ldy; a.act = act;
@@ -516,6 +529,31 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   hipEvent_t e0, e1;
   STTS_HIP(hipEventCreate(&e0));
   STTS_HIP(hipEventCreate(&e1));
+  if (tune & 512) {  // the Winograd F(4, k) form of the same conv, transforms included (k = 3 or 7)
+    stts_ctx tmp;
+    HostTensor hw;
+    hw.shape = {cout, cin, k};
+    hw.data.resize((size_t)cout * cin * k);
+    uint32_t s3 = 4242;
+    for (auto& v : hw.data) { s3 = s3 * 1664525u + 1013904223u; v = (((s3 >> 8) & 0xFFFF) / 32768.0f - 1.0f) * 0.05f; }
+    WinoConv wc;
+    STTS_TRY(pack_winograd(&tmp, hw, nullptr, 0, cin, cout, &wc));
+    float* scratch = nullptr;
+    STTS_HIP(hipMalloc(&scratch, wino_scratch_floats(s, wc) * sizeof(float)));
+    for (int i = 0; i < 2; ++i) STTS_TRY(run_winograd(st, s, X, kc, wc, Y, ldy, 0, nullptr, 0, 1.0f, scratch));
+    STTS_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) STTS_TRY(run_winograd(st, s, X, kc, wc, Y, ldy, 0, nullptr, 0, 1.0f, scratch));
+    STTS_HIP(hipEventRecord(e1, st));
+    STTS_HIP(hipEventSynchronize(e1));
+    float msw = 0;
+    STTS_HIP(hipEventElapsedTime(&msw, e0, e1));
+    *avg_ms = msw / iters;
+    (void)hipFree(scratch);
+    for (void* p : tmp.allocs) (void)hipFree(p);
+    (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(B); (void)hipFree(so);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+  }
   for (int i = 0; i < 2; ++i) STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, npad, n_utt, rows_per_utt, tile));
   STTS_HIP(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i) STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, npad, n_utt, rows_per_utt, tile));

@@ -551,6 +551,11 @@ __global__ void __launch_bounds__(256) euler_step_kernel(float* __restrict__ x, 
   }
 }
 
+// out[i] = i * step, i < n  (segment offsets of equally sized planes)
+__global__ void seg_linear_kernel(int* __restrict__ out, int n, int step) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = i * step;
+}
+
 inline void launch_scale_weight(hipStream_t st, dim3 grid, int prec, const float* W, const float* gx, int ld_gx, const float* gamma, void* Wu, int npad,
                                 int kc) {
   if (prec == PREC_BF16) hipLaunchKernelGGL(scale_weight_kernel<PREC_BF16>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);

@@ -15,6 +15,7 @@
 #include "phoneme.hip.h"
 #include "wn_layer.hip.h"
 #include "wn_layer_small.hip.h"
+#include "winograd.hip.h"
 
 namespace stts {
 
@@ -31,6 +32,14 @@ struct PackedConv {
   float* bias = nullptr;
   int npad = 0, N = 0, kc = 0, ntaps = 1;
   int cin_real = 0, rows_real = 0;  // un-padded sizes (FLOP accounting)
+};
+
+// Winograd F(4, r) form of a 'same' conv (winograd.hip.h): the n weight planes G_j g as one packed tensor [n][npad][1][kc].
+struct WinoConv {
+  PackedConv planes;  // W: n planes of npad x kc (plane stride npad * kc); bias: the conv's own bias [npad]
+  WinoMats mats;
+  int pad = 0;
+  bool ready = false;
 };
 
 // one entry of a style-projection table
@@ -61,6 +70,7 @@ struct StyleTable {
 struct AdainBlockW {
   int cin = 0, cout = 0, kcin = 0;  // kcin = cin padded to 32
   PackedConv conv1, conv2, sc;      // sc.W == nullptr: identity shortcut
+  WinoConv w1;                      // conv1 in Winograd form (fp32 mode, k = 3), used for large batches
   StyleSlot n1, n2;
 };
 
@@ -113,6 +123,7 @@ struct stts_ctx {
   stts::StyleTable flow_style;
   // generator
   stts::PackedConv amp_prior, phase_prior, proj_mel, proj_la, proj_ph, amp_out, phase_out;  // *_out: the first n_fft/2 channels
+  stts::WinoConv wino_prior[2], wino_out[2];  // the four k = 7 convs of the vocoder in Winograd form (fp32 mode)
   float* nyq_w[2] = {nullptr, nullptr};  // last (Nyquist) output channel of amp/phase output convs, [taps][cin]
   float nyq_b[2] = {0.f, 0.f};
   stts::ConvNextW cnx[4];
@@ -279,11 +290,54 @@ inline int add_style(stts_ctx* c, StyleTable* t, const std::string& p, int C, St
   return 0;
 }
 
+inline int pack_winograd(stts_ctx* c, const HostTensor& w, const HostTensor* bias, int cin_lo, int cin_n, int cout_used, WinoConv* out) {
+  const int cin = (int)w.shape[1], r = (int)w.shape[2];
+  STTS_CHECK(wino_matrices(r, &out->mats), "winograd: unsupported kernel size %d (or self-check failed)", r);
+  const int n = out->mats.n, npad = round_up(cout_used, 128), kc = round_up(cin_n, 32);
+  HostTensor wp;
+  wp.shape = {(int64_t)n * cout_used, cin, 1};
+  wp.data.assign((size_t)n * cout_used * cin, 0.f);
+  for (int j = 0; j < n; ++j)
+    for (int co = 0; co < cout_used; ++co)
+      for (int ci = 0; ci < cin; ++ci) {
+        double acc = 0;
+        for (int k = 0; k < r; ++k) acc += out->mats.G[j][k] * (double)w.data[((size_t)co * cin + ci) * r + k];
+        wp.data[((size_t)j * cout_used + co) * cin + ci] = (float)acc;
+      }
+  std::vector<int> row_of((size_t)n * npad, -1);
+  for (int j = 0; j < n; ++j)
+    for (int co = 0; co < cout_used; ++co) row_of[(size_t)j * npad + co] = j * cout_used + co;
+  const int saved_prec = c->prec;
+  c->prec = PREC_F32;  // the transformed weights span ~3 decades (G up to 729): fp32 operands only
+  const int rc = pack_rows(c, wp, nullptr, row_of, cin_lo, cin_n, kc, cout_used, &out->planes);
+  c->prec = saved_prec;
+  STTS_TRY(rc);
+  out->planes.npad = npad;
+  out->planes.cin_real = cin_n;
+  out->planes.rows_real = cout_used;
+  if (bias) {
+    std::vector<float> pb(npad, 0.f);
+    for (int co = 0; co < cout_used; ++co) pb[co] = bias->data[co];
+    STTS_TRY(dev_upload(c, pb, &out->planes.bias));
+  } else {
+    out->planes.bias = nullptr;
+  }
+  out->pad = (r - 1) / 2;
+  out->ready = true;
+  return 0;
+}
+
 inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout, StyleTable* table, AdainBlockW* o) {
   o->cin = cin;
   o->cout = cout;
   o->kcin = round_up(cin, 32);
   STTS_TRY(pack_plain(c, p + ".conv1", true, 0, cin, &o->conv1));
+  o->w1 = WinoConv();
+  if (c->prec == PREC_F32) {
+    HostTensor w1;
+    STTS_TRY(get_weight(c, p + ".conv1", &w1));
+    if (w1.shape[2] == 3) STTS_TRY(pack_winograd(c, w1, find(c, p + ".conv1.bias"), 0, cin, cout, &o->w1));
+  }
   STTS_TRY(pack_plain(c, p + ".conv2", true, 0, cout, &o->conv2));
   if (find(c, p + ".conv1x1.parametrizations.weight.original0") || find(c, p + ".conv1x1.weight"))
     STTS_TRY(pack_plain(c, p + ".conv1x1", false, 0, cin, &o->sc));
@@ -386,6 +440,15 @@ inline int finalize_frame(stts_ctx* c, int which) {
     const int h = d.gen_hidden, hp = h / 2;
     STTS_TRY(pack_plain(c, g + "amp_prior_conv", true, 0, kBins, &c->amp_prior));
     STTS_TRY(pack_plain(c, g + "phase_prior_conv", true, 0, kBins, &c->phase_prior));
+    for (int q = 0; q < 2; ++q) c->wino_prior[q] = c->wino_out[q] = WinoConv();
+    if (c->prec == PREC_F32) {
+      for (int q = 0; q < 2; ++q) {
+        const std::string nm = g + (q == 0 ? "amp_prior_conv" : "phase_prior_conv");
+        HostTensor wq;
+        STTS_TRY(get_weight(c, nm, &wq));
+        if (wq.shape[2] == 7) STTS_TRY(pack_winograd(c, wq, find(c, nm + ".bias"), 0, kBins, hp, &c->wino_prior[q]));
+      }
+    }
     STTS_TRY(pack_plain(c, g + "projector", true, 0, d.gen_input, &c->proj_mel));
     STTS_TRY(pack_plain(c, g + "projector", false, d.gen_input, hp, &c->proj_la));
     STTS_TRY(pack_plain(c, g + "projector", false, d.gen_input + hp, hp, &c->proj_ph));
@@ -398,6 +461,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
       const int nmain = kBins - 1, ci = (int)w.shape[1], kk = (int)w.shape[2];
       STTS_CHECK((int)w.shape[0] == kBins && ci == h + hp, "%s: unexpected shape", nm.c_str());
       STTS_TRY(pack_rows(c, w, b, plain_rows(nmain), 0, ci, round_up(ci, 32), nmain, which == 0 ? &c->amp_out : &c->phase_out));
+      if (c->prec == PREC_F32 && kk == 7) STTS_TRY(pack_winograd(c, w, b, 0, ci, nmain, &c->wino_out[which]));
       std::vector<float> last((size_t)kk * ci);
       for (int t = 0; t < kk; ++t)
         for (int q = 0; q < ci; ++q) last[(size_t)t * ci + q] = w.data[((size_t)nmain * ci + q) * kk + t];
@@ -505,6 +569,48 @@ inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, cons
   if (a.nseg < i + 1) a.nseg = i + 1;
 }
 
+// Y = conv(X) through the Winograd form (winograd.hip.h).  Scratch: wino_scratch_floats(s, wc) floats.
+inline size_t wino_scratch_floats(const Seg& s, const WinoConv& wc) {
+  const long pr = wino_plane_rows(s.rows(), s.n_utt);
+  return (size_t)wc.mats.n * pr * (wc.planes.kc + round_up(wc.planes.N, 32)) + 64;
+}
+template <int N>
+inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
+                          float alpha, float* scratch) {
+  const int n = wc.mats.n, kc = wc.planes.kc, ldm = round_up(wc.planes.N, 32), ml = s.max_len();
+  const long pr = wino_plane_rows(s.rows(), s.n_utt);
+  float* Xp = scratch;
+  float* Mp = Xp + (size_t)n * pr * kc;
+  int* segp = reinterpret_cast<int*>(Mp + (size_t)n * pr * ldm);  // [n + 1] plane offsets: the contraction's "utterances"
+  WinoIn ti;
+  WinoOut to;
+  memcpy(ti.Bt, wc.mats.Bt, sizeof(ti.Bt));
+  memcpy(to.At, wc.mats.At, sizeof(to.At));
+  const int groups = ceil_div(ml, kWinoM);
+  hipLaunchKernelGGL(seg_linear_kernel, dim3(1), dim3(64), 0, st, segp, n + 1, (int)pr);
+  hipLaunchKernelGGL((winograd_input_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(kc / 4, 64), s.n_utt), dim3(64, 4), 0, st, X, ldx,
+                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, pr);
+  std::vector<int> seg_h(n + 1);
+  for (int j = 0; j <= n; ++j) seg_h[j] = (int)(j * pr);
+  Seg sp{n, seg_h.data(), segp};
+  GemmArgs a = gemm_args(sp);
+  set_seg(a, 0, Xp, kc, 0, wc.planes, 0);
+  a.seg[0].w_utt_stride = (long)wc.planes.npad * kc;
+  a.N = wc.planes.N; a.bias = nullptr; a.Y = Mp; a.ldy = ldm;
+  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, wc.planes.npad, n, (int)pr));
+  hipLaunchKernelGGL((winograd_output_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(ceil_div(wc.planes.N, 4), 64), s.n_utt), dim3(64, 4), 0, st, Mp, ldm, pr,
+                     s.dev, to, wc.planes.bias, act, R, ldr, alpha, Y, ldy, wc.planes.N);
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
+                        float alpha, float* scratch) {
+  STTS_CHECK(wc.ready && (wc.mats.n == 6 || wc.mats.n == 10), "winograd conv not packed");
+  STTS_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "winograd conv: leading dimensions must be multiples of 4");
+  return wc.mats.n == 6 ? run_winograd_n<6>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch)
+                        : run_winograd_n<10>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch);
+}
+
 inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
   hipLaunchKernelGGL(style_fc_kernel, dim3(ceil_div(t.J, 4)), dim3(256), 0, st, t.W, t.b, style, out, t.J, t.K, n_utt, t.K, t.ld());
   STTS_HIP(hipGetLastError());
@@ -533,7 +639,7 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
 // kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
 // scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [adain_part_floats(s, max(kcin, cout))]
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
-                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0) {
+                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, float* wino = nullptr) {
   const int ml = s.max_len();
   // Small batches (launch-latency bound): AdaIN -> LeakyReLU is folded into the staging of the contraction that consumes
   // it (conv_gemm_f32<..., XAFF>): the statistics pass stays, a 64-thread kernel turns them into per-(utterance, channel)
@@ -563,7 +669,12 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   a.bias = B.conv1.bias;
   a.Y = hbuf;
   a.ldy = B.cout;
-  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
+  if (!fold && wino && B.w1.ready && force_tile == 0) {
+    // large batches: conv1 (k = 3) in Winograd F(4,3) form, half the multiplies (winograd.hip.h)
+    STTS_TRY(run_winograd(st, s, act1, B.kcin, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, wino));
+  } else {
+    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
+  }
   // norm2 -> LeakyReLU -> conv2 (+ learned 1x1 shortcut as a second K segment | + identity residual), / sqrt(2)
   GemmArgs b = gemm_args(s);
   if (fold) {
@@ -608,6 +719,8 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* act2 = ws.get<float>(R * d.dec_hidden);
   float* ss = ws.get<float>(adain_part_floats(s, ldcat));
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
+  // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
+  float* wino = (R > 4096 && c->dec[1].w1.ready) ? ws.get<float>(wino_scratch_floats(s, c->dec[1].w1)) : nullptr;
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
   FrontArgs fa;
@@ -625,13 +738,13 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->asr_res.npad, s.n_utt, s.max_len()));
   }
   const int lds = c->dec_style.ld();
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss));
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, wino));
   float* cur = xa;
   float* nxt = xb;
   for (int i = 1; i <= 4; ++i) {
     float* dst = i == 4 ? x_out : nxt;
     const int ldd = i == 4 ? ld_x : ldcat;
-    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss));
+    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, wino));
     std::swap(cur, nxt);
   }
   return 0;
@@ -753,9 +866,11 @@ inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows
 
 // prior convs (generator.py:412-413) write straight into the concat slots [h, h+hp) of the two head inputs.  The two
 // convs are independent (and independent of decoder/flow), so the caller may put them on different streams.
-inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head) {
+inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, float* wino = nullptr) {
   const int h = c->d.gen_hidden, hp = h / 2, hc = h + hp;
   const PackedConv& w = which == 0 ? c->amp_prior : c->phase_prior;
+  if (wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(4,7) form: 10 instead of 28 multiplies per 4 outputs
+    return run_winograd(st, s, har, ld_har, c->wino_prior[which], head + h, hc, ACT_NONE, nullptr, 0, 1.0f, wino);
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, har, ld_har, 0, w);
   a.N = hp; a.bias = w.bias; a.Y = head; a.ldy = hc; a.ycol0 = h;
@@ -785,6 +900,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   float* ph = phase_out ? phase_out : ws.get<float>(R * ldlp);
   const int ldl = logamp_out ? ld_lp : ldlp;
   float* yw = ws.get<float>((R + s.n_utt) * kWin);
+  float* wino = (c->wino_out[0].ready && c->wino_out[1].ready) ? ws.get<float>(wino_scratch_floats(s, c->wino_out[0])) : nullptr;
   STTS_CHECK(ws.ok, "vocoder: workspace too small");
   STTS_CHECK(!logamp_out == !phase_out, "logamp_out and phase_out must be given together");
   const int lds = c->gen_style.ld();
@@ -832,11 +948,13 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     GemmArgs a = gemm_args(s);
     set_seg(a, 0, headA, hc, 0, c->amp_out);
     a.N = kBins - 1; a.bias = c->amp_out.bias; a.Y = la; a.ldy = ldl;
-    STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->amp_out.npad, s.n_utt, ml));
+    if (wino) STTS_TRY(run_winograd(st, s, headA, hc, c->wino_out[0], la, ldl, ACT_NONE, nullptr, 0, 1.0f, wino));
+    else STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->amp_out.npad, s.n_utt, ml));
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, headP, hc, 0, c->phase_out);
     b.N = kBins - 1; b.bias = c->phase_out.bias; b.Y = ph; b.ldy = ldl;
-    STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
+    if (wino) STTS_TRY(run_winograd(st, s, headP, hc, c->wino_out[1], ph, ldl, ACT_NONE, nullptr, 0, 1.0f, wino));
+    else STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
     const int kk = c->amp_out.ntaps;
     hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), 0, st, headA, hc, hc, s.dev, row_utt, c->nyq_w[0],
                        c->nyq_b[0], kk, la, ldl, kBins - 1, (int)R);
@@ -856,8 +974,13 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* headA = ws.get<float>(R * hc);
   float* headP = ws.get<float>(R * hc);
   STTS_CHECK(ws.ok, "vocoder_forward: workspace too small");
-  STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA));
-  STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP));
+  {
+    Arena tmp(ws.base + ws.used, ws.cap - ws.used);  // released again before vocoder_body carves its own buffers
+    float* wino = c->wino_prior[0].ready ? tmp.get<float>(wino_scratch_floats(s, c->wino_prior[0])) : nullptr;
+    STTS_CHECK(tmp.ok, "vocoder_forward: workspace too small");
+    STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, wino));
+    STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, wino));
+  }
   return vocoder_body(c, st, s, mel, ld_mel, style, headA, headP, audio, logamp_out, phase_out, ld_lp, ws);
 }
 
@@ -865,10 +988,12 @@ inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int
   // closed form upper bound: the largest stage (vocoder) + the stage hand-off buffers + per-buffer alignment slack
   const stts_model_dims& d = c->d;
   const size_t f = sizeof(float);
-  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f;
+  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / 4 + n_utt + 1) * 6 * (608 + 512) * f + 4096;
   const size_t flow = (size_t)R * 128 * 4 * f;
   const size_t src = (size_t)R * (8 + kHop * f);
-  const size_t voc = (size_t)R * ((512 + 256) * 2 + 512 * 4 + d.gen_inter + 1056 * 2 + 1 + kWin) * f + (size_t)n_utt * kWin * f;
+  // Winograd scratch (fp32 mode): 10 component planes of R/4 + n_utt + 1 rows x (768 in + 1024 out) for the output convs
+  const size_t wino = ((size_t)R / 4 + n_utt + 1) * 10 * (1056 + 1024) * f + 4096;
+  const size_t voc = (size_t)R * ((512 + 256) * 2 + 512 * 4 + d.gen_inter + 1056 * 2 + 1 + kWin) * f + (size_t)n_utt * kWin * f + wino;
   const size_t per_utt = (size_t)n_utt * ((size_t)(ceil_div(max_len, 128) * 4 + 1) * d.gen_inter + 512 * (size_t)d.gen_inter + 32768) * f;
   const size_t handoff = (size_t)R * (512 + 512 + 1056 * 2 + 768 * 2 + kHop + 2) * f;
   return std::max(std::max(dec, flow), std::max(src, voc)) + handoff + per_utt + (size_t)64 * 4096;
@@ -906,8 +1031,13 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   // Measured: running the (independent) source -> STFT -> prior-conv chain on side streams next to decoder/flow gains
   // < 1 % at B = 8 (7.51 vs 7.57 ms/step): the decoder GEMMs already fill the chip, so the stages stay on one stream.
   { Arena a(side_ws, side_bytes); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a)); }
-  STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA));
-  STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP));
+  {
+    Arena a = stage();
+    float* wino = c->wino_prior[0].ready ? a.get<float>(wino_scratch_floats(s, c->wino_prior[0])) : nullptr;
+    STTS_CHECK(a.ok, "frame_path: workspace too small");
+    STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, wino));
+    STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, wino));
+  }
   { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, 512, a)); }
   { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, 512, style, prior_noise, mel, 512, nullptr, nullptr, a)); }
   { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, 512, style, headA, headP, audio, nullptr, nullptr, 0, a)); }

@@ -1,0 +1,167 @@
+// 1-D Winograd / Toom-Cook fast convolution F(4, r) over the TIME axis for the wide 'same' convolutions of the frame path
+// (stride 1, dilation 1, r = 3 or 7 taps).  Four consecutive outputs of a channel need 4 + r - 1 inputs and, computed as
+//   y = A^T [ (G g) (.) (B^T d) ],
+// only n = 4 + r - 1 products per input channel instead of 4 r:  r = 7 -> 10 instead of 28 (x 0.357), r = 3 -> 6 of 12.
+// The sum over input channels of each of the n component products is an ordinary contraction, so the work is
+//   1. winograd_input_kernel : X [rows, cin] -> X' [n][groups, cin]   (B^T d per group of 4 output rows; zeros outside
+//                              the utterance = the conv's zero padding)
+//   2. conv_gemm_f32         : n independent 1-tap contractions [groups, cin] x [cin, cout], one weight plane G_j g per
+//                              component (the launcher's per-utterance-weights mode: component = "utterance")
+//   3. winograd_output_kernel: M [n][groups, cout] -> Y [rows, cout] = A^T M (+ bias, activation, residual, scale)
+// Matrices come from the evaluation points {0, +-1, +-2, (+-1/2, +-3,) inf} (Cook-Toom), built in double on the host and
+// validated against direct correlation at start-up; the fp32 error of F(4,7) is ~5e-6 of the output scale (direct: 3e-7),
+// far inside the path's 2e-4 / 1e-3 parity bars.
+// Group g of utterance u lives at row  seg_off[u] / 4 + u + g  of every component plane (no prefix sum needed; at most
+// one unused row per utterance, whose garbage never leaves its own row of the contraction).
+#pragma once
+#include <array>
+#include <cmath>
+#include <vector>
+
+#include "gemm.hip.h"
+
+namespace stts {
+
+constexpr int kWinoM = 4;       // outputs per group
+constexpr int kWinoMaxN = 10;   // components of F(4,7)
+
+struct WinoMats {
+  int r = 0, n = 0;
+  float Bt[kWinoMaxN][kWinoMaxN];  // input transform  [component][input row of the group]
+  float At[kWinoM][kWinoMaxN];     // output transform [output row of the group][component]
+  double G[kWinoMaxN][8];          // weight transform [component][tap] (host only)
+};
+
+// polynomial helpers (coefficients low -> high)
+inline std::vector<double> wino_polymul(const std::vector<double>& a, const std::vector<double>& b) {
+  std::vector<double> c(a.size() + b.size() - 1, 0.0);
+  for (size_t i = 0; i < a.size(); ++i)
+    for (size_t j = 0; j < b.size(); ++j) c[i + j] += a[i] * b[j];
+  return c;
+}
+
+// F(4, r): returns false for an unsupported r or if the self-check against direct correlation fails
+inline bool wino_matrices(int r, WinoMats* out) {
+  std::vector<double> pts;
+  if (r == 3) pts = {0, 1, -1, 2, -2};
+  else if (r == 7) pts = {0, 1, -1, 2, -2, 0.5, -0.5, 3, -3};
+  else return false;
+  const int m = kWinoM, n = m + r - 1;
+  std::vector<std::vector<double>> A(n, std::vector<double>(m, 0.0)), G(n, std::vector<double>(r, 0.0)), C(n, std::vector<double>(n, 0.0));
+  for (int j = 0; j < n - 1; ++j) {
+    for (int i = 0; i < m; ++i) A[j][i] = std::pow(pts[j], i);
+    for (int k = 0; k < r; ++k) G[j][k] = std::pow(pts[j], k);
+    std::vector<double> num{1.0};
+    double den = 1.0;
+    for (int l = 0; l < n - 1; ++l)
+      if (l != j) {
+        num = wino_polymul(num, {-pts[l], 1.0});
+        den *= pts[j] - pts[l];
+      }
+    for (size_t q = 0; q < num.size(); ++q) C[q][j] = num[q] / den;  // Lagrange basis polynomial of point j
+  }
+  A[n - 1][m - 1] = 1.0;
+  G[n - 1][r - 1] = 1.0;
+  std::vector<double> M{1.0};
+  for (int l = 0; l < n - 1; ++l) M = wino_polymul(M, {-pts[l], 1.0});
+  for (int q = 0; q < n; ++q) C[q][n - 1] = M[q];
+  out->r = r;
+  out->n = n;
+  for (int j = 0; j < kWinoMaxN; ++j)
+    for (int q = 0; q < kWinoMaxN; ++q) out->Bt[j][q] = (j < n && q < n) ? (float)C[q][j] : 0.0f;
+  for (int i = 0; i < kWinoM; ++i)
+    for (int j = 0; j < kWinoMaxN; ++j) out->At[i][j] = j < n ? (float)A[j][i] : 0.0f;
+  for (int j = 0; j < kWinoMaxN; ++j)
+    for (int k = 0; k < 8; ++k) out->G[j][k] = (j < n && k < r) ? G[j][k] : 0.0;
+  // self-check: y_i = sum_k g_k d_{i+k}
+  std::vector<double> g(r), d(n);
+  for (int k = 0; k < r; ++k) g[k] = std::sin(1.0 + k);
+  for (int q = 0; q < n; ++q) d[q] = std::cos(0.3 + 1.7 * q);
+  for (int i = 0; i < m; ++i) {
+    double ref = 0, y = 0;
+    for (int k = 0; k < r; ++k) ref += g[k] * d[i + k];
+    for (int j = 0; j < n; ++j) {
+      double gg = 0, dd = 0;
+      for (int k = 0; k < r; ++k) gg += G[j][k] * g[k];
+      for (int q = 0; q < n; ++q) dd += C[q][j] * d[q];
+      y += A[j][i] * gg * dd;
+    }
+    if (std::fabs(y - ref) > 1e-9 * (1.0 + std::fabs(ref))) return false;
+  }
+  return true;
+}
+
+struct WinoIn {
+  float Bt[kWinoMaxN][kWinoMaxN];
+};
+struct WinoOut {
+  float At[kWinoM][kWinoMaxN];
+};
+
+// rows of a component plane for a batch of `rows` frames in n_utt utterances
+inline long wino_plane_rows(long rows, int n_utt) { return rows / kWinoM + n_utt + 1; }
+
+// grid (ceil(max groups / 4), ceil(C4 / 64), n_utt), block (64, 4): thread = 4 channels of one group
+template <int N>
+__global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off, int pad,
+                                                             const WinoIn t, float* __restrict__ Xp, int ldp, long plane_rows) {
+  const int u = blockIdx.z;
+  const int lo = seg_off[u], len = seg_off[u + 1] - lo;
+  const int groups = (len + kWinoM - 1) / kWinoM;
+  const int g = blockIdx.x * 4 + threadIdx.y;
+  const int c4 = (blockIdx.y * 64 + threadIdx.x) * 4;
+  if (g >= groups || c4 >= ldp) return;
+  f32x4 d[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const int row = g * kWinoM - pad + q;
+    d[q] = (row >= 0 && row < len && c4 < C) ? *reinterpret_cast<const f32x4*>(X + (long)(lo + row) * ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long prow = lo / kWinoM + u + g;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < N; ++q) v += t.Bt[j][q] * d[q];
+    *reinterpret_cast<f32x4*>(Xp + ((long)j * plane_rows + prow) * ldp + c4) = v;
+  }
+}
+
+// Y[row][n] = (act(sum_j At[i][j] M_j[group][n] + bias[n]) [+ R[row][n]]) * alpha for the rows of each group inside its utterance
+template <int N>
+__global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ Mp, int ldm, long plane_rows, const int* __restrict__ seg_off,
+                                                              const WinoOut t, const float* __restrict__ bias, int act, const float* __restrict__ R,
+                                                              int ldr, float alpha, float* __restrict__ Y, int ldy, int Nout) {
+  const int u = blockIdx.z;
+  const int lo = seg_off[u], len = seg_off[u + 1] - lo;
+  const int groups = (len + kWinoM - 1) / kWinoM;
+  const int g = blockIdx.x * 4 + threadIdx.y;
+  const int n4 = (blockIdx.y * 64 + threadIdx.x) * 4;
+  if (g >= groups || n4 >= Nout) return;
+  const long prow = lo / kWinoM + u + g;
+  f32x4 m[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) m[j] = *reinterpret_cast<const f32x4*>(Mp + ((long)j * plane_rows + prow) * ldm + n4);
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (bias) b = *reinterpret_cast<const f32x4*>(bias + n4);
+#pragma unroll
+  for (int i = 0; i < kWinoM; ++i) {
+    const int row = g * kWinoM + i;
+    if (row < len) {
+      f32x4 v = b;
+#pragma unroll
+      for (int j = 0; j < N; ++j) v += t.At[i][j] * m[j];
+      float* y = Y + (long)(lo + row) * ldy + n4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (n4 + c < Nout) {
+          float e = act_apply(v[c], act);
+          if (R) e += R[(long)(lo + row) * ldr + n4 + c];
+          y[c] = e * alpha;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace stts

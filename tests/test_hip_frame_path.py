@@ -275,3 +275,35 @@ def test_mrf_block_golden(hip):
     s = segs([96])
     y = hip.op_mrf_block("mrf.", s, tm(g["x"]), 128, 7, dev(g["style"]))
     close(cm(y, 1, 128, 96), g["y"], what="AdaptiveGeneratorBlock")
+
+
+@pytest.mark.parametrize(
+    "cin,cout,k,lengths",
+    [
+        (64, 128, 3, [40]),
+        (96, 130, 7, [50, 333]),
+        (578, 512, 3, [200, 37, 129, 4, 1, 2, 3]),  # lengths not multiples of the 4-row groups, shorter than the kernel
+        (768, 1024, 7, [131, 76]),
+        (1025, 256, 7, [77]),
+    ],
+)
+def test_conv1d_winograd_matches_oracle(hip, cin, cout, k, lengths):
+    """The F(4, k) Winograd form (input transform -> one 1-tap contraction per component -> output transform) against the
+    direct convolution of the oracle.  fp32 error of F(4,7) is ~5e-6 of the output scale (winograd.hip.h)."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+
+    s = segs(lengths)
+    ld = (cin + 31) // 32 * 32
+    w = (synth.normal(f"wg.w.{cin}.{cout}.{k}", (cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    b = synth.normal(f"wg.b.{cout}", (cout,))
+    xs = [synth.normal(f"wg.x.{i}.{L}", (1, cin, L)) for i, L in enumerate(lengths)]
+    x = np.zeros((s.rows, ld), np.float32)
+    for i, xi in enumerate(xs):
+        x[s.host[i] : s.host[i + 1], :cin] = xi[0].T
+    y = hip.op_conv1d(s, dev(x), cin, w, b, force_tile=-4).cpu().numpy()
+    y_direct = hip.op_conv1d(s, dev(x), cin, w, b).cpu().numpy()
+    for i, xi in enumerate(xs):
+        ref = O.conv1d(xi, w, b, padding=(k - 1) // 2)[0].T
+        close(y[s.host[i] : s.host[i + 1], :cout], ref, rtol=3e-5, what=f"winograd conv utt {i}")
+        close(y[s.host[i] : s.host[i + 1], :cout], y_direct[s.host[i] : s.host[i + 1], :cout], rtol=3e-5, what=f"winograd vs direct utt {i}")

@@ -57,7 +57,9 @@ def test_cfg2_batch8_is_deterministic_and_equals_single_utterances(hip):
         lo, hi = 960 * u, 960 * (u + 1)
         one = run(hip, [960], slice_inputs(x, lo, hi, u))
         err = float((one - a[75 * lo : 75 * hi]).abs().max())
-        assert err < 2e-5, (u, err)  # tile shapes differ between B = 1 and B = 8 launches -> fp32 summation order only
+        # the batch uses the Winograd form of the wide convs and other tiles than a single utterance does: fp32 rounding
+        # differences only (F(4,7): ~5e-6 of the conv's scale), two decades inside the 1e-3 parity bar
+        assert err < 1e-4, (u, err)
 
 
 def test_cfg4_ragged_256_utterances(hip):
@@ -73,7 +75,7 @@ def test_cfg4_ragged_256_utterances(hip):
         lo, hi = int(off[u]), int(off[u + 1])
         one = run(hip, [lengths[u]], slice_inputs(x, lo, hi, u))
         err = float((one - a[75 * lo : 75 * hi]).abs().max())
-        assert err < 2e-5, (u, lengths[u], err)
+        assert err < 1e-4, (u, lengths[u], err)
 
 
 def test_cfg5_long_form_10s_batch(hip):
@@ -83,7 +85,7 @@ def test_cfg5_long_form_10s_batch(hip):
     a = run(hip, lengths, x)
     assert bool(torch.isfinite(a).all())
     one = run(hip, [3200], slice_inputs(x, 3200 * 5, 3200 * 6, 5))
-    assert float((one - a[75 * 3200 * 5 : 75 * 3200 * 6]).abs().max()) < 2e-5
+    assert float((one - a[75 * 3200 * 5 : 75 * 3200 * 6]).abs().max()) < 1e-4
 
 
 def test_batch_scope_changes_only_the_harmonic_count(hip):
