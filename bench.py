@@ -200,7 +200,7 @@ def main():
             except Exception:
                 traffic = None
         out["roofline"] = {
-            "kernel": "conv_gemm_f32 + wn_layer_kernel (all Conv1d/Linear contractions of the step)",
+            "kernel": "conv_gemm_f32 + wn_layer_kernel (all Conv1d/Linear contractions of the step; Winograd-form convs timed with their transforms)",
             "bound": "mfma",
             "achieved": round(achieved, 2),
             "peak": MFMA_PEAK_TFLOPS[args.precision],

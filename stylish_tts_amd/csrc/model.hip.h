@@ -572,24 +572,35 @@ inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, cons
 // Y = conv(X) through the Winograd form (winograd.hip.h).  Scratch: wino_scratch_floats(s, wc) floats.
 inline size_t wino_scratch_floats(const Seg& s, const WinoConv& wc) {
   const long pr = wino_plane_rows(s.rows(), s.n_utt);
-  return (size_t)wc.mats.n * pr * (wc.planes.kc + round_up(wc.planes.N, 32)) + 64;
+  return (size_t)wc.mats.n * pr * (wc.planes.kc + round_up(wc.planes.N, 32)) + 32 + s.n_utt + 8;
 }
 template <int N>
 inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
                           float alpha, float* scratch) {
   const int n = wc.mats.n, kc = wc.planes.kc, ldm = round_up(wc.planes.N, 32), ml = s.max_len();
-  const long pr = wino_plane_rows(s.rows(), s.n_utt);
+  long pr = 0;  // rows of a component plane: the groups of 4 output rows of all utterances, packed
+  for (int u = 0; u < s.n_utt; ++u) pr += ceil_div(s.host[u + 1] - s.host[u], kWinoM);
+  const long pr_cap = wino_plane_rows(s.rows(), s.n_utt);
   float* Xp = scratch;
-  float* Mp = Xp + (size_t)n * pr * kc;
-  int* segp = reinterpret_cast<int*>(Mp + (size_t)n * pr * ldm);  // [n + 1] plane offsets: the contraction's "utterances"
+  float* Mp = Xp + (size_t)n * pr_cap * kc;
+  int* segp = reinterpret_cast<int*>(Mp + (size_t)n * pr_cap * ldm);  // [n + 1] plane offsets: the contraction's "utterances"
+  int* goff = segp + 16;                                                // [n_utt + 1] first group of every utterance
   WinoIn ti;
   WinoOut to;
   memcpy(ti.Bt, wc.mats.Bt, sizeof(ti.Bt));
   memcpy(to.At, wc.mats.At, sizeof(to.At));
   const int groups = ceil_div(ml, kWinoM);
-  hipLaunchKernelGGL(seg_linear_kernel, dim3(1), dim3(64), 0, st, segp, n + 1, (int)pr);
+  // measurement (bench.py roofline leg): the conv is timed as a whole (both transforms + contraction, stream markers) and
+  // credited with the ALGORITHMIC flops of the direct convolution, 2 * rows * cout * cin * taps
+  GemmProfiler& prof = gemm_profiler();
+  const bool timed = prof.on;
+  if (timed) {
+    (void)hipEventRecord(prof.next(), st);
+    prof.on = false;
+  }
+  hipLaunchKernelGGL(wino_setup_kernel, dim3(1), dim3(64), 0, st, s.dev, s.n_utt, n, goff, segp);
   hipLaunchKernelGGL((winograd_input_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(kc / 4, 64), s.n_utt), dim3(64, 4), 0, st, X, ldx,
-                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, pr);
+                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff);
   std::vector<int> seg_h(n + 1);
   for (int j = 0; j <= n; ++j) seg_h[j] = (int)(j * pr);
   Seg sp{n, seg_h.data(), segp};
@@ -597,9 +608,20 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   set_seg(a, 0, Xp, kc, 0, wc.planes, 0);
   a.seg[0].w_utt_stride = (long)wc.planes.npad * kc;
   a.N = wc.planes.N; a.bias = nullptr; a.Y = Mp; a.ldy = ldm;
-  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, wc.planes.npad, n, (int)pr));
-  hipLaunchKernelGGL((winograd_output_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(ceil_div(wc.planes.N, 4), 64), s.n_utt), dim3(64, 4), 0, st, Mp, ldm, pr,
+  {
+    const int rc = launch_conv_gemm(st, a, EPI_STORE, wc.planes.npad, n, (int)pr);
+    if (rc) {
+      prof.on = timed;
+      return rc;
+    }
+  }
+  hipLaunchKernelGGL((winograd_output_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(ceil_div(wc.planes.N, 4), 64), s.n_utt), dim3(64, 4), 0, st, Mp, ldm, goff,
                      s.dev, to, wc.planes.bias, act, R, ldr, alpha, Y, ldy, wc.planes.N);
+  if (timed) {
+    prof.on = true;
+    (void)hipEventRecord(prof.next(), st);
+    prof.flops.push_back(2.0 * (double)s.rows() * wc.planes.rows_real * wc.planes.cin_real * wc.mats.r);
+  }
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -988,11 +1010,11 @@ inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int
   // closed form upper bound: the largest stage (vocoder) + the stage hand-off buffers + per-buffer alignment slack
   const stts_model_dims& d = c->d;
   const size_t f = sizeof(float);
-  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / 4 + n_utt + 1) * 6 * (608 + 512) * f + 4096;
+  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / 4 + n_utt + 1) * 6 * (608 + 512) * f + ((size_t)n_utt + 1024) * f;
   const size_t flow = (size_t)R * 128 * 4 * f;
   const size_t src = (size_t)R * (8 + kHop * f);
   // Winograd scratch (fp32 mode): 10 component planes of R/4 + n_utt + 1 rows x (768 in + 1024 out) for the output convs
-  const size_t wino = ((size_t)R / 4 + n_utt + 1) * 10 * (1056 + 1024) * f + 4096;
+  const size_t wino = ((size_t)R / 4 + n_utt + 1) * 10 * (1056 + 1024) * f + ((size_t)n_utt + 1024) * f;
   const size_t voc = (size_t)R * ((512 + 256) * 2 + 512 * 4 + d.gen_inter + 1056 * 2 + 1 + kWin) * f + (size_t)n_utt * kWin * f + wino;
   const size_t per_utt = (size_t)n_utt * ((size_t)(ceil_div(max_len, 128) * 4 + 1) * d.gen_inter + 512 * (size_t)d.gen_inter + 32768) * f;
   const size_t handoff = (size_t)R * (512 + 512 + 1056 * 2 + 768 * 2 + kHop + 2) * f;

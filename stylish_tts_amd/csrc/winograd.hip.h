@@ -11,8 +11,8 @@
 // Matrices come from the evaluation points {0, +-1, +-2, (+-1/2, +-3,) inf} (Cook-Toom), built in double on the host and
 // validated against direct correlation at start-up; the fp32 error of F(4,7) is ~5e-6 of the output scale (direct: 3e-7),
 // far inside the path's 2e-4 / 1e-3 parity bars.
-// Group g of utterance u lives at row  seg_off[u] / 4 + u + g  of every component plane (no prefix sum needed; at most
-// one unused row per utterance, whose garbage never leaves its own row of the contraction).
+// Group g of utterance u lives at row goff[u] + g of every component plane, goff = prefix sum of ceil(len / 4)
+// (wino_setup_kernel): the planes are packed exactly, so the contraction's row tiles carry no padding beyond the last one.
 #pragma once
 #include <array>
 #include <cmath>
@@ -98,13 +98,33 @@ struct WinoOut {
   float At[kWinoM][kWinoMaxN];
 };
 
-// rows of a component plane for a batch of `rows` frames in n_utt utterances
+// upper bound of the rows of a component plane for a batch of `rows` frames in n_utt utterances (scratch sizing)
 inline long wino_plane_rows(long rows, int n_utt) { return rows / kWinoM + n_utt + 1; }
+
+// one block: goff[u] = sum_{v<u} ceil(len_v / 4) (n_utt + 1 entries) and the plane offsets segp[j] = j * goff[n_utt], j <= n
+__global__ void __launch_bounds__(64) wino_setup_kernel(const int* __restrict__ seg_off, int n_utt, int n, int* __restrict__ goff, int* __restrict__ segp) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int u0 = 0; u0 < n_utt; u0 += 64) {
+    const int u = u0 + lane;
+    const int g = u < n_utt ? (seg_off[u + 1] - seg_off[u] + kWinoM - 1) / kWinoM : 0;
+    int incl = g;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    if (u < n_utt) goff[u] = base + incl - g;
+    base += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) goff[n_utt] = base;
+  for (int j = lane; j <= n; j += 64) segp[j] = j * base;
+}
 
 // grid (ceil(max groups / 4), ceil(C4 / 64), n_utt), block (64, 4): thread = 4 channels of one group
 template <int N>
 __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off, int pad,
-                                                             const WinoIn t, float* __restrict__ Xp, int ldp, long plane_rows) {
+                                                             const WinoIn t, float* __restrict__ Xp, int ldp, const int* __restrict__ goff) {
   const int u = blockIdx.z;
   const int lo = seg_off[u], len = seg_off[u + 1] - lo;
   const int groups = (len + kWinoM - 1) / kWinoM;
@@ -117,7 +137,7 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
     const int row = g * kWinoM - pad + q;
     d[q] = (row >= 0 && row < len && c4 < C) ? *reinterpret_cast<const f32x4*>(X + (long)(lo + row) * ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const long prow = lo / kWinoM + u + g;
+  const long prow = goff[u] + g, plane_rows = goff[gridDim.z];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -129,7 +149,7 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 
 // Y[row][n] = (act(sum_j At[i][j] M_j[group][n] + bias[n]) [+ R[row][n]]) * alpha for the rows of each group inside its utterance
 template <int N>
-__global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ Mp, int ldm, long plane_rows, const int* __restrict__ seg_off,
+__global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ Mp, int ldm, const int* __restrict__ goff, const int* __restrict__ seg_off,
                                                               const WinoOut t, const float* __restrict__ bias, int act, const float* __restrict__ R,
                                                               int ldr, float alpha, float* __restrict__ Y, int ldy, int Nout) {
   const int u = blockIdx.z;
@@ -138,7 +158,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
   const int g = blockIdx.x * 4 + threadIdx.y;
   const int n4 = (blockIdx.y * 64 + threadIdx.x) * 4;
   if (g >= groups || n4 >= Nout) return;
-  const long prow = lo / kWinoM + u + g;
+  const long prow = goff[u] + g, plane_rows = goff[gridDim.z];
   f32x4 m[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) m[j] = *reinterpret_cast<const f32x4*>(Mp + ((long)j * plane_rows + prow) * ldm + n4);

@@ -13,16 +13,18 @@ def collect(sub, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        if "conv_gemm_f32" in k or "wn_layer_kernel" in k:
+        if "conv_gemm_f32" in k or "wn_layer" in k:
             tot += float(r["Counter_Value"])
             n += 1
+        elif "winograd_" in k:  # transforms of a Winograd-form conv: same logical launch as its contraction
+            tot += float(r["Counter_Value"])
     return tot, n
 
 
 fetch, nf = collect("pmc_fetch", "FETCH_SIZE")
 write, nw = collect("pmc_write", "WRITE_SIZE")
 res = {
-    "kernels": "conv_gemm_f32 + wn_layer_kernel",
+    "kernels": "conv_gemm_f32 + wn_layer_kernel (+ Winograd transforms)",
     "launches_sampled": nf,
     "fetch_bytes_per_launch_corrected_x2": int(fetch * 1024 * 2 / nf),
     "write_bytes_per_launch": int(write * 1024 / nw),
