@@ -70,7 +70,7 @@ struct StyleTable {
 struct AdainBlockW {
   int cin = 0, cout = 0, kcin = 0;  // kcin = cin padded to 32
   PackedConv conv1, conv2, sc;      // sc.W == nullptr: identity shortcut
-  WinoConv w1;                      // conv1 in Winograd form (fp32 mode, k = 3), used for large batches
+  WinoConv w1, w2;                  // conv1 / conv2 (identity-shortcut blocks only) in Winograd form (fp32 mode, k = 3), large batches
   StyleSlot n1, n2;
 };
 
@@ -339,8 +339,14 @@ inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout
     if (w1.shape[2] == 3) STTS_TRY(pack_winograd(c, w1, find(c, p + ".conv1.bias"), 0, cin, cout, &o->w1));
   }
   STTS_TRY(pack_plain(c, p + ".conv2", true, 0, cout, &o->conv2));
-  if (find(c, p + ".conv1x1.parametrizations.weight.original0") || find(c, p + ".conv1x1.weight"))
+  o->w2 = WinoConv();
+  if (find(c, p + ".conv1x1.parametrizations.weight.original0") || find(c, p + ".conv1x1.weight")) {
     STTS_TRY(pack_plain(c, p + ".conv1x1", false, 0, cin, &o->sc));
+  } else if (c->prec == PREC_F32) {  // identity shortcut: conv2 is a plain conv + residual, so it has a Winograd form too
+    HostTensor w2;
+    STTS_TRY(get_weight(c, p + ".conv2", &w2));
+    if (w2.shape[2] == 3) STTS_TRY(pack_winograd(c, w2, find(c, p + ".conv2.bias"), 0, cout, cout, &o->w2));
+  }
   STTS_TRY(add_style(c, table, p + ".norm1", cin, &o->n1));
   STTS_TRY(add_style(c, table, p + ".norm2", cout, &o->n2));
   return 0;
@@ -719,7 +725,11 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   b.Y = y;
   b.ldy = ldy;
   b.alpha = 0.70710678118654752440f;
-  STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
+  if (!fold && wino && B.w2.ready && !B.sc.W && force_tile == 0) {
+    STTS_TRY(run_winograd(st, s, act2, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, wino));
+  } else {
+    STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
+  }
   STTS_HIP(hipGetLastError());
   return 0;
 }

@@ -402,7 +402,7 @@ inline size_t phoneme_workspace_bytes(const stts_ctx* c, int64_t n_tok, int64_t 
   const stts_model_dims& d = c->d;
   const size_t C = d.te_hidden, Cp = d.pe_inter + d.style_dim;
   const size_t tok = (size_t)n_tok * (C * 8 + d.te_filter + Cp * 12 + d.style_dim * 12 + 64) * sizeof(float);
-  const size_t frm = (size_t)n_frames * (Cp * 12 + 16) * sizeof(float);
+  const size_t frm = (size_t)n_frames * (Cp * 12 + 16) * sizeof(float) + ((size_t)n_frames / 4 + n_utt + 1) * 6 * 2 * Cp * sizeof(float);  // + Winograd scratch
   const size_t per = (size_t)n_utt * ((size_t)(n_tok / std::max(1, n_utt) / 32 + 16) * 4 * d.style_dim * 8 + 128 * 256 + 8192) * sizeof(float);
   return tok + frm + per + ((size_t)4 << 20);
 }
@@ -456,6 +456,7 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
   float* hb = ws.get<float>(Rf * C);
   float* act2 = ws.get<float>(Rf * C);
   float* ss = ws.get<float>(adain_part_floats(sf, C));
+  float* wino = (Rf > 4096 && P.f0[0].w1.ready) ? ws.get<float>(wino_scratch_floats(sf, P.f0[0].w1)) : nullptr;  // large batches: Winograd convs
   STTS_CHECK(ws.ok, "pitch_energy_forward: workspace too small");
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sp.max_len(), 256), sp.n_utt), dim3(256), 0, st, sp.dev, sp.n_utt, row_utt_p);
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sf.max_len(), 256), sf.n_utt), dim3(256), 0, st, sf.dev, sf.n_utt, row_utt_f);
@@ -484,7 +485,7 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
     const float* cur = x;
     float* bufs[2] = {t1, t2};
     for (int i = 0; i < 3; ++i) {
-      STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss));
+      STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss, 0, wino));
       cur = bufs[i & 1];
     }
     hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)Rf, 4)), dim3(256), 0, st, cur, C, C, sf.dev, row_utt_f,
