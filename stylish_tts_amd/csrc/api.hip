@@ -362,7 +362,9 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
     float* scratch = nullptr;
     STTS_HIP(hipMalloc(&scratch, wino_scratch_floats(s, wc) * sizeof(float)));
     tmp.allocs.push_back(scratch);
-    int r = run_winograd(st, s, x, ldx, wc, y, ldy, act, nullptr, 0, 1.0f, scratch);
+    WinoScratch wz;
+    wz.p = scratch;
+    int r = run_winograd(st, s, x, ldx, wc, y, ldy, act, nullptr, 0, 1.0f, wz);
     hipError_t e = hipStreamSynchronize(st);
     for (void* p : tmp.allocs) (void)hipFree(p);
     STTS_HIP(e);
@@ -540,9 +542,11 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
     STTS_TRY(pack_winograd(&tmp, hw, nullptr, 0, cin, cout, &wc));
     float* scratch = nullptr;
     STTS_HIP(hipMalloc(&scratch, wino_scratch_floats(s, wc) * sizeof(float)));
-    for (int i = 0; i < 2; ++i) STTS_TRY(run_winograd(st, s, X, kc, wc, Y, ldy, 0, nullptr, 0, 1.0f, scratch));
+    WinoScratch wz;
+    wz.p = scratch;
+    for (int i = 0; i < 2; ++i) STTS_TRY(run_winograd(st, s, X, kc, wc, Y, ldy, 0, nullptr, 0, 1.0f, wz));
     STTS_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) STTS_TRY(run_winograd(st, s, X, kc, wc, Y, ldy, 0, nullptr, 0, 1.0f, scratch));
+    for (int i = 0; i < iters; ++i) STTS_TRY(run_winograd(st, s, X, kc, wc, Y, ldy, 0, nullptr, 0, 1.0f, wz));
     STTS_HIP(hipEventRecord(e1, st));
     STTS_HIP(hipEventSynchronize(e1));
     float msw = 0;

@@ -575,22 +575,28 @@ inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, cons
   if (a.nseg < i + 1) a.nseg = i + 1;
 }
 
-// Y = conv(X) through the Winograd form (winograd.hip.h).  Scratch: wino_scratch_floats(s, wc) floats.
+// Y = conv(X) through the Winograd form (winograd.hip.h).  Scratch: wino_scratch_floats(s, wc) floats; its head holds the
+// group offsets of the batch (wino_setup_kernel), computed once per scratch and shared by every conv that uses it.
+struct WinoScratch {
+  float* p = nullptr;
+  bool setup = false;
+  explicit operator bool() const { return p != nullptr; }
+};
 inline size_t wino_scratch_floats(const Seg& s, const WinoConv& wc) {
   const long pr = wino_plane_rows(s.rows(), s.n_utt);
-  return (size_t)wc.mats.n * pr * (wc.planes.kc + round_up(wc.planes.N, 32)) + 32 + s.n_utt + 8;
+  return (size_t)wc.mats.n * pr * (wc.planes.kc + round_up(wc.planes.N, 32)) + round_up(s.n_utt + 1 + 16, 32) + 32;
 }
 template <int N>
 inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
-                          float alpha, float* scratch) {
+                          float alpha, WinoScratch& scratch) {
   const int n = wc.mats.n, kc = wc.planes.kc, ldm = round_up(wc.planes.N, 32), ml = s.max_len();
   long pr = 0;  // rows of a component plane: the groups of 4 output rows of all utterances, packed
   for (int u = 0; u < s.n_utt; ++u) pr += ceil_div(s.host[u + 1] - s.host[u], kWinoM);
   const long pr_cap = wino_plane_rows(s.rows(), s.n_utt);
-  float* Xp = scratch;
+  int* segp = reinterpret_cast<int*>(scratch.p);  // [kWinoMaxN + 1] plane offsets j * plane rows: the contraction's "utterances"
+  int* goff = segp + 16;                          // [n_utt + 1] first group of every utterance
+  float* Xp = scratch.p + round_up(s.n_utt + 1 + 16, 32);
   float* Mp = Xp + (size_t)n * pr_cap * kc;
-  int* segp = reinterpret_cast<int*>(Mp + (size_t)n * pr_cap * ldm);  // [n + 1] plane offsets: the contraction's "utterances"
-  int* goff = segp + 16;                                                // [n_utt + 1] first group of every utterance
   WinoIn ti;
   WinoOut to;
   memcpy(ti.Bt, wc.mats.Bt, sizeof(ti.Bt));
@@ -604,7 +610,10 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
     (void)hipEventRecord(prof.next(), st);
     prof.on = false;
   }
-  hipLaunchKernelGGL(wino_setup_kernel, dim3(1), dim3(64), 0, st, s.dev, s.n_utt, n, goff, segp);
+  if (!scratch.setup) {
+    hipLaunchKernelGGL(wino_setup_kernel, dim3(1), dim3(64), 0, st, s.dev, s.n_utt, kWinoMaxN, goff, segp);
+    scratch.setup = true;
+  }
   hipLaunchKernelGGL((winograd_input_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(kc / 4, 64), s.n_utt), dim3(64, 4), 0, st, X, ldx,
                      wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff);
   std::vector<int> seg_h(n + 1);
@@ -632,7 +641,7 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   return 0;
 }
 inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
-                        float alpha, float* scratch) {
+                        float alpha, WinoScratch& scratch) {
   STTS_CHECK(wc.ready && (wc.mats.n == 6 || wc.mats.n == 10), "winograd conv not packed");
   STTS_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "winograd conv: leading dimensions must be multiples of 4");
   return wc.mats.n == 6 ? run_winograd_n<6>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch)
@@ -667,7 +676,7 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
 // kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
 // scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [adain_part_floats(s, max(kcin, cout))]
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
-                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, float* wino = nullptr) {
+                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr) {
   const int ml = s.max_len();
   // Small batches (launch-latency bound): AdaIN -> LeakyReLU is folded into the staging of the contraction that consumes
   // it (conv_gemm_f32<..., XAFF>): the statistics pass stays, a 64-thread kernel turns them into per-(utterance, channel)
@@ -697,9 +706,9 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   a.bias = B.conv1.bias;
   a.Y = hbuf;
   a.ldy = B.cout;
-  if (!fold && wino && B.w1.ready && force_tile == 0) {
+  if (!fold && wino && *wino && B.w1.ready && force_tile == 0) {
     // large batches: conv1 (k = 3) in Winograd F(4,3) form, half the multiplies (winograd.hip.h)
-    STTS_TRY(run_winograd(st, s, act1, B.kcin, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, wino));
+    STTS_TRY(run_winograd(st, s, act1, B.kcin, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino));
   } else {
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
   }
@@ -725,8 +734,8 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   b.Y = y;
   b.ldy = ldy;
   b.alpha = 0.70710678118654752440f;
-  if (!fold && wino && B.w2.ready && !B.sc.W && force_tile == 0) {
-    STTS_TRY(run_winograd(st, s, act2, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, wino));
+  if (!fold && wino && *wino && B.w2.ready && !B.sc.W && force_tile == 0) {
+    STTS_TRY(run_winograd(st, s, act2, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, *wino));
   } else {
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
   }
@@ -752,7 +761,8 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* ss = ws.get<float>(adain_part_floats(s, ldcat));
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
-  float* wino = (R > 4096 && c->dec[1].w1.ready) ? ws.get<float>(wino_scratch_floats(s, c->dec[1].w1)) : nullptr;
+  WinoScratch wino;
+  if (R > 4096 && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
   FrontArgs fa;
@@ -770,13 +780,13 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->asr_res.npad, s.n_utt, s.max_len()));
   }
   const int lds = c->dec_style.ld();
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, wino));
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino));
   float* cur = xa;
   float* nxt = xb;
   for (int i = 1; i <= 4; ++i) {
     float* dst = i == 4 ? x_out : nxt;
     const int ldd = i == 4 ? ld_x : ldcat;
-    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, wino));
+    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino));
     std::swap(cur, nxt);
   }
   return 0;
@@ -898,11 +908,11 @@ inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows
 
 // prior convs (generator.py:412-413) write straight into the concat slots [h, h+hp) of the two head inputs.  The two
 // convs are independent (and independent of decoder/flow), so the caller may put them on different streams.
-inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, float* wino = nullptr) {
+inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, WinoScratch* wino = nullptr) {
   const int h = c->d.gen_hidden, hp = h / 2, hc = h + hp;
   const PackedConv& w = which == 0 ? c->amp_prior : c->phase_prior;
-  if (wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(4,7) form: 10 instead of 28 multiplies per 4 outputs
-    return run_winograd(st, s, har, ld_har, c->wino_prior[which], head + h, hc, ACT_NONE, nullptr, 0, 1.0f, wino);
+  if (wino && *wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(4,7) form: 10 instead of 28 multiplies per 4 outputs
+    return run_winograd(st, s, har, ld_har, c->wino_prior[which], head + h, hc, ACT_NONE, nullptr, 0, 1.0f, *wino);
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, har, ld_har, 0, w);
   a.N = hp; a.bias = w.bias; a.Y = head; a.ldy = hc; a.ycol0 = h;
@@ -932,7 +942,8 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   float* ph = phase_out ? phase_out : ws.get<float>(R * ldlp);
   const int ldl = logamp_out ? ld_lp : ldlp;
   float* yw = ws.get<float>((R + s.n_utt) * kWin);
-  float* wino = (c->wino_out[0].ready && c->wino_out[1].ready) ? ws.get<float>(wino_scratch_floats(s, c->wino_out[0])) : nullptr;
+  WinoScratch wino;
+  if (c->wino_out[0].ready && c->wino_out[1].ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->wino_out[0]));
   STTS_CHECK(ws.ok, "vocoder: workspace too small");
   STTS_CHECK(!logamp_out == !phase_out, "logamp_out and phase_out must be given together");
   const int lds = c->gen_style.ld();
@@ -1008,10 +1019,11 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   STTS_CHECK(ws.ok, "vocoder_forward: workspace too small");
   {
     Arena tmp(ws.base + ws.used, ws.cap - ws.used);  // released again before vocoder_body carves its own buffers
-    float* wino = c->wino_prior[0].ready ? tmp.get<float>(wino_scratch_floats(s, c->wino_prior[0])) : nullptr;
+    WinoScratch wino;
+    if (c->wino_prior[0].ready) wino.p = tmp.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
     STTS_CHECK(tmp.ok, "vocoder_forward: workspace too small");
-    STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, wino));
-    STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, wino));
+    STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, &wino));
+    STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, &wino));
   }
   return vocoder_body(c, st, s, mel, ld_mel, style, headA, headP, audio, logamp_out, phase_out, ld_lp, ws);
 }
@@ -1065,10 +1077,11 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   { Arena a(side_ws, side_bytes); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a)); }
   {
     Arena a = stage();
-    float* wino = c->wino_prior[0].ready ? a.get<float>(wino_scratch_floats(s, c->wino_prior[0])) : nullptr;
+    WinoScratch wino;
+    if (c->wino_prior[0].ready) wino.p = a.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
     STTS_CHECK(a.ok, "frame_path: workspace too small");
-    STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, wino));
-    STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, wino));
+    STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino));
+    STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino));
   }
   { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, 512, a)); }
   { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, 512, style, prior_noise, mel, 512, nullptr, nullptr, a)); }

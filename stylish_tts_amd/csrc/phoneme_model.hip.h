@@ -456,7 +456,8 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
   float* hb = ws.get<float>(Rf * C);
   float* act2 = ws.get<float>(Rf * C);
   float* ss = ws.get<float>(adain_part_floats(sf, C));
-  float* wino = (Rf > 4096 && P.f0[0].w1.ready) ? ws.get<float>(wino_scratch_floats(sf, P.f0[0].w1)) : nullptr;  // large batches: Winograd convs
+  WinoScratch wino;  // large batches: Winograd convs
+  if (Rf > 4096 && P.f0[0].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(sf, P.f0[0].w1));
   STTS_CHECK(ws.ok, "pitch_energy_forward: workspace too small");
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sp.max_len(), 256), sp.n_utt), dim3(256), 0, st, sp.dev, sp.n_utt, row_utt_p);
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sf.max_len(), 256), sf.n_utt), dim3(256), 0, st, sf.dev, sf.n_utt, row_utt_f);
@@ -485,7 +486,7 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
     const float* cur = x;
     float* bufs[2] = {t1, t2};
     for (int i = 0; i < 3; ++i) {
-      STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss, 0, wino));
+      STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss, 0, &wino));
       cur = bufs[i & 1];
     }
     hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)Rf, 4)), dim3(256), 0, st, cur, C, C, sf.dev, row_utt_f,
