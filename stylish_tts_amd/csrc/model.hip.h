@@ -291,6 +291,8 @@ inline int add_style(stts_ctx* c, StyleTable* t, const std::string& p, int C, St
 }
 
 inline int pack_winograd(stts_ctx* c, const HostTensor& w, const HostTensor* bias, int cin_lo, int cin_n, int cout_used, WinoConv* out) {
+  static const bool disabled = getenv("STTS_NO_WINOGRAD") != nullptr;  // debugging aid: every conv then runs in its direct form
+  if (disabled) return 0;  // out->ready stays false
   const int cin = (int)w.shape[1], r = (int)w.shape[2];
   STTS_CHECK(wino_matrices(r, &out->mats), "winograd: unsupported kernel size %d (or self-check failed)", r);
   const int n = out->mats.n, npad = round_up(cout_used, 128), kc = round_up(cin_n, 32);
