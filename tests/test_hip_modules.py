@@ -222,3 +222,25 @@ def test_infer_from_phoneme_strings(mods, tmp_path):
         from scipy.io import wavfile
         rate, back = wavfile.read(str(tmp_path / f"sample_{i}.wav"))
         assert rate == 24000 and np.array_equal(back, p)
+
+
+def test_synthesizer_soak_random_batches(mods):
+    """Back-to-back calls with changing batch sizes and lengths (grow-only workspaces, per-stream scratch, side-stream
+    encoders): every waveform finite, in (-1, 1), with the length its predicted frame count implies."""
+    import random
+
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.pipeline import Synthesizer
+
+    eng = mods["speech_predictor"].engine
+    for m in mods.values():
+        m.engine
+    syn = Synthesizer(eng)
+    rnd = random.Random(7)
+    for it in range(24):
+        B = rnd.choice([1, 2, 3, 5, 8])
+        toks = [synth.tokens(f"soak.{it}.{i}", 1, rnd.randint(4, 40), 178)[0].tolist() for i in range(B)]
+        waves, det = syn(toks, return_details=True)
+        assert len(waves) == B
+        for w, T in zip(waves, det["frames"]):
+            assert w.numel() == 300 * T and bool(torch.isfinite(w).all()) and float(w.abs().max()) < 1.0
