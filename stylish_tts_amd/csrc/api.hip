@@ -41,10 +41,6 @@ int stts_ctx_create(const stts_model_dims* dims, int device, stts_ctx** out) {
 void stts_ctx_destroy(stts_ctx* c) {
   if (!c) return;
   for (void* p : c->allocs) (void)hipFree(p);
-  for (int i = 0; i < 2; ++i)
-    if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
-  for (int i = 0; i < 4; ++i)
-    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
 }
 

@@ -134,8 +134,6 @@ struct stts_ctx {
   std::map<std::string, std::unique_ptr<stts::StyleTable>> op_tables;
   std::map<std::string, std::unique_ptr<stts::MrfW>> op_mrf;
   std::shared_ptr<void> phoneme;  // stts::PhonemeModel (phoneme_model.hip.h)
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace stts {
@@ -1043,15 +1041,6 @@ inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int
   const size_t per_utt = (size_t)n_utt * ((size_t)(ceil_div(max_len, 128) * 4 + 1) * d.gen_inter + 512 * (size_t)d.gen_inter + 32768) * f;
   const size_t handoff = (size_t)R * (512 + 512 + 1056 * 2 + 768 * 2 + kHop + 2) * f;
   return std::max(std::max(dec, flow), std::max(src, voc)) + handoff + per_utt + (size_t)64 * 4096;
-}
-
-// The harmonic source -> STFT -> prior convs chain does not depend on decoder/flow (it only needs the pitch), so it runs
-// on two side streams next to them and joins before the projector: it fills SIMD slots the small flow GEMMs leave idle.
-inline int ensure_side_streams(stts_ctx* c) {
-  if (c->side[0]) return 0;
-  for (int i = 0; i < 2; ++i) STTS_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-  for (int i = 0; i < 4; ++i) STTS_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
-  return 0;
 }
 
 inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* asr, int ld_asr, const float* pitch, const float* energy,
