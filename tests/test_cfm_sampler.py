@@ -39,7 +39,7 @@ def test_oracle_matches_reference_sampler(n):
 @pytest.mark.parametrize("n", STEPS)
 def test_hip_sampler_matches_reference(n):
     torch = pytest.importorskip("torch")
-    from stylish_tts_amd.cfm import CfmSampler
+    from stylish_tts_amd.euler_sampler import CfmSampler
 
     g = load_golden("cfm_euler")
     z, cond = torch.from_numpy(g[f"z{n}"]).cuda(), torch.from_numpy(g[f"cond{n}"]).cuda()
