@@ -10,8 +10,8 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); rank 0 broa
 every rank runs its own batch (weak scaling, utterances are independent) and the waveforms are gathered to rank 0
 inside the timed step.  Rank 0 prints ONE JSON line.
 
-Extra legs (rank 0, N = 1): `roofline` for the dominant kernel (conv_gemm_f32) from HIP events bracketing every
-launch on its own stream in a profiling pass right after the timed region, and `cpu_baseline` = the numpy oracle
+Extra legs (rank 0, N = 1): `roofline` for the dominant kernels (conv_gemm_f32 + wn_layer_kernel) from HIP start/stop events on
+every launch on its own stream in a profiling pass right after the timed region, and `cpu_baseline` = the numpy oracle
 timed on the host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
@@ -226,12 +226,19 @@ def main():
                 nzb = dict(prior_noise=h["nz"]["prior_noise"][bb : bb + 1], src_noise=h["nz"]["src_noise"][bb : bb + 1], init_phase=h["nz"]["init_phase"])
                 O.frame_path(h["asr"][sl].T[None].copy(), h["pitch"][sl][None], h["energy"][sl][None], h["style"][bb : bb + 1], nzb, sd)
             cpu_t = time.perf_counter() - t1
+            try:  # the threads the oracle's matrix products actually ran on
+                from threadpoolctl import threadpool_info
+
+                blas_threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+            except Exception:
+                blas_threads = os.cpu_count()
             out["cpu_baseline"] = {
                 "value": round(n_utts / cpu_t, 4),
                 "unit": "utt/s",
-                "cores": os.cpu_count(),
+                "cores": blas_threads,
                 "kind": "port",
-                "sample": f"{n_utts} utterances of the same workload (3.0 s each, B=1 per call), numpy oracle (BLAS threads = host default)",
+                "sample": f"{n_utts} utterances of the same workload (3.0 s each, B=1 per call), numpy oracle; BLAS pool = {blas_threads} threads "
+                          f"of {os.cpu_count()} logical cores",
                 "reference_torch_cpu_note": "survey container, 8 vCPU, reference torch-CPU code: 1.4 utt/s at B=1, 1.9-2.5 utt/s at B=8 (BASELINE.md §2)",
             }
     if rank == 0:
