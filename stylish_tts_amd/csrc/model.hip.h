@@ -817,6 +817,19 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   if (z_prior_out) STTS_HIP(hipMemcpyAsync(z_prior_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
   // reversed(flows) = Flip, layer 7, Flip, layer 6, ..., Flip, layer 0: after k flips the roles of the halves swap,
   // so layer f reads half p = (f odd) and updates the other half in place; after layer 0 the order is natural.
+  // 32-row or 16-row blocks for the fused WaveNet layer (fp32): one block per CU is resident, so a launch takes
+  // ceil(blocks / 256) rounds of ~38 us (32 rows) or ~21 us (16 rows: half the MFMA chain, but the weight staging per
+  // block is the same).  B = 8: 240 x 38 us beats 480 blocks = 2 x 21; B = 12: 720 blocks = 3 x 21 beats 360 = 2 x 38.
+  bool rows16 = false;
+  if (c->prec == PREC_F32) {
+    long b32 = 0, b16 = 0;
+    for (int u = 0; u < s.n_utt; ++u) {
+      const int len = s.host[u + 1] - s.host[u];
+      b32 += ceil_div(len, 32);
+      b16 += ceil_div(len, 16);
+    }
+    rows16 = ceil_div((int)b16, 256) * 21 < ceil_div((int)b32, 256) * 38;
+  }
   auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
   for (int f = 7; f >= 0; --f) {
     const FlowLayerW& L = c->flow[f];
@@ -858,7 +871,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       }
       const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
       // small batches (fp32): 16-row blocks, twice the workgroups at half the chain length (wn_layer_small.hip.h)
-      if (c->prec == PREC_F32 && R <= 4096) STTS_LAUNCH_TIMED(wn_layer_rows16_kernel, dim3(ceil_div(ml, 16), s.n_utt), dim3(1024), st, e0, e1, w);
+      if (rows16) STTS_LAUNCH_TIMED(wn_layer_rows16_kernel, dim3(ceil_div(ml, 16), s.n_utt), dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_BF16>, wgrid, dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_F16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F16>, wgrid, dim3(1024), st, e0, e1, w);
       else STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F32>, wgrid, dim3(1024), st, e0, e1, w);
