@@ -136,6 +136,11 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
   for (int q = 0; q < N; ++q) {
     const int row = g * kWinoM - pad + q;
     d[q] = (row >= 0 && row < len && c4 < C) ? *reinterpret_cast<const f32x4*>(X + (long)(lo + row) * ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c4 + 3 >= C) {  // the channel count need not be a multiple of 4: pad columns of X may hold anything
+#pragma unroll
+      for (int e = 1; e < 4; ++e)
+        if (c4 + e >= C) d[q][e] = 0.0f;
+    }
   }
   const long prow = goff[u] + g, plane_rows = goff[gridDim.z];
 #pragma unroll
