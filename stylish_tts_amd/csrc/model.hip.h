@@ -588,7 +588,7 @@ inline size_t wino_scratch_floats(const Seg& s, const WinoConv& wc) {
 }
 template <int N>
 inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
-                          float alpha, WinoScratch& scratch) {
+                          float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0) {
   const int n = wc.mats.n, kc = wc.planes.kc, ldm = round_up(wc.planes.N, 32), ml = s.max_len();
   long pr = 0;  // rows of a component plane: the groups of 4 output rows of all utterances, packed
   for (int u = 0; u < s.n_utt; ++u) pr += ceil_div(s.host[u + 1] - s.host[u], kWinoM);
@@ -615,7 +615,7 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
     scratch.setup = true;
   }
   hipLaunchKernelGGL((winograd_input_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(kc / 4, 64), s.n_utt), dim3(64, 4), 0, st, X, ldx,
-                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff);
+                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff, aff, ld_aff);
   std::vector<int> seg_h(n + 1);
   for (int j = 0; j <= n; ++j) seg_h[j] = (int)(j * pr);
   Seg sp{n, seg_h.data(), segp};
@@ -641,11 +641,11 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   return 0;
 }
 inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
-                        float alpha, WinoScratch& scratch) {
+                        float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0) {
   STTS_CHECK(wc.ready && (wc.mats.n == 6 || wc.mats.n == 10), "winograd conv not packed");
   STTS_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "winograd conv: leading dimensions must be multiples of 4");
-  return wc.mats.n == 6 ? run_winograd_n<6>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch)
-                        : run_winograd_n<10>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch);
+  return wc.mats.n == 6 ? run_winograd_n<6>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff)
+                        : run_winograd_n<10>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff);
 }
 
 inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
@@ -698,7 +698,10 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     set_seg(a, 0, x, ldx, 0, B.conv1);
     a.xaff = act1;
     a.ld_xaff = B.kcin;
-  } else {
+  }
+  const bool wino1 = !fold && wino && *wino && B.w1.ready && force_tile == 0;
+  const bool wino2 = !fold && wino && *wino && B.w2.ready && !B.sc.W && force_tile == 0;
+  if (!fold && !wino1) {
     STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ss));
     set_seg(a, 0, act1, B.kcin, 0, B.conv1);
   }
@@ -706,9 +709,11 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   a.bias = B.conv1.bias;
   a.Y = hbuf;
   a.ldy = B.cout;
-  if (!fold && wino && *wino && B.w1.ready && force_tile == 0) {
-    // large batches: conv1 (k = 3) in Winograd F(4,3) form, half the multiplies (winograd.hip.h)
-    STTS_TRY(run_winograd(st, s, act1, B.kcin, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino));
+  if (wino1) {
+    // large batches: conv1 (k = 3) in Winograd F(4,3) form, half the multiplies (winograd.hip.h); AdaIN + LeakyReLU ride
+    // in its input transform (an elementwise, bandwidth-bound kernel: there the affine is free, unlike in the K loop)
+    affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1);
+    STTS_TRY(run_winograd(st, s, x, ldx, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino, act1, B.kcin));
   } else {
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
   }
@@ -719,6 +724,8 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     set_seg(b, 0, hbuf, B.cout, 0, B.conv2);
     b.xaff = act2;
     b.ld_xaff = B.cout;
+  } else if (wino2) {
+    affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2);
   } else {
     STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, ss));
     set_seg(b, 0, act2, B.cout, 0, B.conv2);
@@ -734,8 +741,8 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   b.Y = y;
   b.ldy = ldy;
   b.alpha = 0.70710678118654752440f;
-  if (!fold && wino && *wino && B.w2.ready && !B.sc.W && force_tile == 0) {
-    STTS_TRY(run_winograd(st, s, act2, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, *wino));
+  if (wino2) {
+    STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, *wino, act2, B.cout));
   } else {
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
   }

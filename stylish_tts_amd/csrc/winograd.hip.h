@@ -124,18 +124,35 @@ __global__ void __launch_bounds__(64) wino_setup_kernel(const int* __restrict__ 
 // grid (ceil(max groups / 4), ceil(C4 / 64), n_utt), block (64, 4): thread = 4 channels of one group
 template <int N>
 __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off, int pad,
-                                                             const WinoIn t, float* __restrict__ Xp, int ldp, const int* __restrict__ goff) {
+                                                             const WinoIn t, float* __restrict__ Xp, int ldp, const int* __restrict__ goff,
+                                                             const float* __restrict__ aff, int ld_aff) {
   const int u = blockIdx.z;
   const int lo = seg_off[u], len = seg_off[u + 1] - lo;
   const int groups = (len + kWinoM - 1) / kWinoM;
   const int g = blockIdx.x * 4 + threadIdx.y;
   const int c4 = (blockIdx.y * 64 + threadIdx.x) * 4;
   if (g >= groups || c4 >= ldp) return;
+  // aff (optional): the conv's input is lrelu_0.2(x * scale + shift) with per-(utterance, channel) scale / shift rows
+  // (AdaIN folded into this transform: adain_affine_kernel).  Rows outside the utterance stay zero (the conv pads the
+  // activated tensor), scale 0 marks a pad channel.
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (aff && c4 < C) {
+    sc = *reinterpret_cast<const f32x4*>(aff + ((long)u * 2) * ld_aff + c4);
+    sh = *reinterpret_cast<const f32x4*>(aff + ((long)u * 2 + 1) * ld_aff + c4);
+  }
   f32x4 d[N];
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     const int row = g * kWinoM - pad + q;
-    d[q] = (row >= 0 && row < len && c4 < C) ? *reinterpret_cast<const f32x4*>(X + (long)(lo + row) * ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool in = row >= 0 && row < len && c4 < C;
+    d[q] = in ? *reinterpret_cast<const f32x4*>(X + (long)(lo + row) * ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (aff && in) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = (sc[e] == 0.0f ? 0.0f : d[q][e] * sc[e]) + sh[e];
+        d[q][e] = y >= 0.0f ? y : 0.2f * y;
+      }
+    }
     if (c4 + 3 >= C) {  // the channel count need not be a multiple of 4: pad columns of X may hold anything
 #pragma unroll
       for (int e = 1; e < 4; ++e)
