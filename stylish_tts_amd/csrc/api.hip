@@ -351,7 +351,7 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   b.shape = {cout};
   if (bias_host) b.data.assign(bias_host, bias_host + cout);
   Seg s{n_utt, seg_off_host, seg_off_dev};
-  if (force_tile == -4) {  // the Winograd F(4, k) form (k = 3 or 7, dilation 1): winograd.hip.h
+  if (force_tile == -4) {  // the Winograd F(6, k) form (k = 3 or 7, dilation 1): winograd.hip.h
     STTS_CHECK(dil == 1 && precision == 0, "op_conv1d: the Winograd form is fp32, dilation 1");
     WinoConv wc;
     STTS_TRY(pack_winograd(&tmp, w, bias_host ? &b : nullptr, 0, cin, cout, &wc));
@@ -527,7 +527,7 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   hipEvent_t e0, e1;
   STTS_HIP(hipEventCreate(&e0));
   STTS_HIP(hipEventCreate(&e1));
-  if (tune & 512) {  // the Winograd F(4, k) form of the same conv, transforms included (k = 3 or 7)
+  if (tune & 512) {  // the Winograd F(6, k) form of the same conv, transforms included (k = 3 or 7)
     stts_ctx tmp;
     HostTensor hw;
     hw.shape = {cout, cin, k};

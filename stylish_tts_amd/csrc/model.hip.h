@@ -34,7 +34,7 @@ struct PackedConv {
   int cin_real = 0, rows_real = 0;  // un-padded sizes (FLOP accounting)
 };
 
-// Winograd F(4, r) form of a 'same' conv (winograd.hip.h): the n weight planes G_j g as one packed tensor [n][npad][1][kc].
+// Winograd F(6, r) form of a 'same' conv (winograd.hip.h): the n weight planes G_j g as one packed tensor [n][npad][1][kc].
 struct WinoConv {
   PackedConv planes;  // W: n planes of npad x kc (plane stride npad * kc); bias: the conv's own bias [npad]
   WinoMats mats;
@@ -642,10 +642,10 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
 }
 inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
                         float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0) {
-  STTS_CHECK(wc.ready && (wc.mats.n == 6 || wc.mats.n == 10), "winograd conv not packed");
+  STTS_CHECK(wc.ready && (wc.mats.n == 8 || wc.mats.n == 12), "winograd conv not packed");
   STTS_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "winograd conv: leading dimensions must be multiples of 4");
-  return wc.mats.n == 6 ? run_winograd_n<6>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff)
-                        : run_winograd_n<10>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff);
+  return wc.mats.n == 8 ? run_winograd_n<8>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff)
+                        : run_winograd_n<12>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff);
 }
 
 inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
@@ -710,7 +710,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   a.Y = hbuf;
   a.ldy = B.cout;
   if (wino1) {
-    // large batches: conv1 (k = 3) in Winograd F(4,3) form, half the multiplies (winograd.hip.h); AdaIN + LeakyReLU ride
+    // large batches: conv1 (k = 3) in Winograd F(6,3) form, 8 instead of 18 multiplies per 6 outputs (winograd.hip.h); AdaIN + LeakyReLU ride
     // in its input transform (an elementwise, bandwidth-bound kernel: there the affine is free, unlike in the K loop)
     affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1);
     STTS_TRY(run_winograd(st, s, x, ldx, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino, act1, B.kcin));
@@ -931,7 +931,7 @@ inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows
 inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, WinoScratch* wino = nullptr) {
   const int h = c->d.gen_hidden, hp = h / 2, hc = h + hp;
   const PackedConv& w = which == 0 ? c->amp_prior : c->phase_prior;
-  if (wino && *wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(4,7) form: 10 instead of 28 multiplies per 4 outputs
+  if (wino && *wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(6,7) form: 12 instead of 42 multiplies per 6 outputs
     return run_winograd(st, s, har, ld_har, c->wino_prior[which], head + h, hc, ACT_NONE, nullptr, 0, 1.0f, *wino);
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, har, ld_har, 0, w);
@@ -1052,11 +1052,11 @@ inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int
   // closed form upper bound: the largest stage (vocoder) + the stage hand-off buffers + per-buffer alignment slack
   const stts_model_dims& d = c->d;
   const size_t f = sizeof(float);
-  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / 4 + n_utt + 1) * 6 * (608 + 512) * f + ((size_t)n_utt + 1024) * f;
+  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / kWinoM + n_utt + 1) * 8 * (608 + 512) * f + ((size_t)n_utt + 1024) * f;
   const size_t flow = (size_t)R * 128 * 4 * f;
   const size_t src = (size_t)R * (8 + kHop * f);
-  // Winograd scratch (fp32 mode): 10 component planes of R/4 + n_utt + 1 rows x (768 in + 1024 out) for the output convs
-  const size_t wino = ((size_t)R / 4 + n_utt + 1) * 10 * (1056 + 1024) * f + ((size_t)n_utt + 1024) * f;
+  // Winograd scratch (fp32 mode): 12 component planes of R/6 + n_utt + 1 rows x (768 in + 1024 out) for the output convs
+  const size_t wino = ((size_t)R / kWinoM + n_utt + 1) * kWinoMaxN * (1056 + 1024) * f + ((size_t)n_utt + 1024) * f;
   const size_t voc = (size_t)R * ((512 + 256) * 2 + 512 * 4 + d.gen_inter + 1056 * 2 + 1 + kWin) * f + (size_t)n_utt * kWin * f + wino;
   const size_t per_utt = (size_t)n_utt * ((size_t)(ceil_div(max_len, 128) * 4 + 1) * d.gen_inter + 512 * (size_t)d.gen_inter + 32768) * f;
   const size_t handoff = (size_t)R * (512 + 512 + 1056 * 2 + 768 * 2 + kHop + 2) * f;

@@ -402,7 +402,7 @@ inline size_t phoneme_workspace_bytes(const stts_ctx* c, int64_t n_tok, int64_t 
   const stts_model_dims& d = c->d;
   const size_t C = d.te_hidden, Cp = d.pe_inter + d.style_dim;
   const size_t tok = (size_t)n_tok * (C * 8 + d.te_filter + Cp * 12 + d.style_dim * 12 + 64) * sizeof(float);
-  const size_t frm = (size_t)n_frames * (Cp * 12 + 16) * sizeof(float) + ((size_t)n_frames / 4 + n_utt + 1) * 6 * 2 * Cp * sizeof(float);  // + Winograd scratch
+  const size_t frm = (size_t)n_frames * (Cp * 12 + 16) * sizeof(float) + ((size_t)n_frames / kWinoM + n_utt + 1) * 8 * 2 * Cp * sizeof(float);  // + Winograd scratch
   const size_t per = (size_t)n_utt * ((size_t)(n_tok / std::max(1, n_utt) / 32 + 16) * 4 * d.style_dim * 8 + 128 * 256 + 8192) * sizeof(float);
   return tok + frm + per + ((size_t)4 << 20);
 }

@@ -1,17 +1,17 @@
-// 1-D Winograd / Toom-Cook fast convolution F(4, r) over the TIME axis for the wide 'same' convolutions of the frame path
-// (stride 1, dilation 1, r = 3 or 7 taps).  Four consecutive outputs of a channel need 4 + r - 1 inputs and, computed as
+// 1-D Winograd / Toom-Cook fast convolution F(6, r) over the TIME axis for the wide 'same' convolutions of the frame path
+// (stride 1, dilation 1, r = 3 or 7 taps).  Six consecutive outputs of a channel need 6 + r - 1 inputs and, computed as
 //   y = A^T [ (G g) (.) (B^T d) ],
-// only n = 4 + r - 1 products per input channel instead of 4 r:  r = 7 -> 10 instead of 28 (x 0.357), r = 3 -> 6 of 12.
+// only n = 6 + r - 1 products per input channel instead of 6 r:  r = 7 -> 12 instead of 42 (x 0.286), r = 3 -> 8 of 18.
 // The sum over input channels of each of the n component products is an ordinary contraction, so the work is
-//   1. winograd_input_kernel : X [rows, cin] -> X' [n][groups, cin]   (B^T d per group of 4 output rows; zeros outside
+//   1. winograd_input_kernel : X [rows, cin] -> X' [n][groups, cin]   (B^T d per group of 6 output rows; zeros outside
 //                              the utterance = the conv's zero padding)
 //   2. conv_gemm_f32         : n independent 1-tap contractions [groups, cin] x [cin, cout], one weight plane G_j g per
 //                              component (the launcher's per-utterance-weights mode: component = "utterance")
 //   3. winograd_output_kernel: M [n][groups, cout] -> Y [rows, cout] = A^T M (+ bias, activation, residual, scale)
-// Matrices come from the evaluation points {0, +-1, +-2, (+-1/2, +-3,) inf} (Cook-Toom), built in double on the host and
-// validated against direct correlation at start-up; the fp32 error of F(4,7) is ~5e-6 of the output scale (direct: 3e-7),
-// far inside the path's 2e-4 / 1e-3 parity bars.
-// Group g of utterance u lives at row goff[u] + g of every component plane, goff = prefix sum of ceil(len / 4)
+// Matrices come from the evaluation points {0, +-1, +-2, +-1/2, (+-3/2, +-3/4,) inf} (Cook-Toom), built in double on the
+// host and validated against direct correlation at start-up; the fp32 error of F(6,7) with these points is ~3e-6 of the
+// output scale (direct: 3e-7; F(4,7) with {.., +-3} was 5e-6), far inside the path's 2e-4 / 1e-3 parity bars.
+// Group g of utterance u lives at row goff[u] + g of every component plane, goff = prefix sum of ceil(len / 6)
 // (wino_setup_kernel): the planes are packed exactly, so the contraction's row tiles carry no padding beyond the last one.
 #pragma once
 #include <array>
@@ -22,8 +22,8 @@
 
 namespace stts {
 
-constexpr int kWinoM = 4;       // outputs per group
-constexpr int kWinoMaxN = 10;   // components of F(4,7)
+constexpr int kWinoM = 6;       // outputs per group
+constexpr int kWinoMaxN = 12;   // components of F(6,7)
 
 struct WinoMats {
   int r = 0, n = 0;
@@ -40,11 +40,11 @@ inline std::vector<double> wino_polymul(const std::vector<double>& a, const std:
   return c;
 }
 
-// F(4, r): returns false for an unsupported r or if the self-check against direct correlation fails
+// F(6, r): returns false for an unsupported r or if the self-check against direct correlation fails
 inline bool wino_matrices(int r, WinoMats* out) {
   std::vector<double> pts;
-  if (r == 3) pts = {0, 1, -1, 2, -2};
-  else if (r == 7) pts = {0, 1, -1, 2, -2, 0.5, -0.5, 3, -3};
+  if (r == 3) pts = {0, 1, -1, 2, -2, 0.5, -0.5};
+  else if (r == 7) pts = {0, 1, -1, 2, -2, 0.5, -0.5, 1.5, -1.5, 0.75, -0.75};
   else return false;
   const int m = kWinoM, n = m + r - 1;
   std::vector<std::vector<double>> A(n, std::vector<double>(m, 0.0)), G(n, std::vector<double>(r, 0.0)), C(n, std::vector<double>(n, 0.0));
@@ -101,7 +101,7 @@ struct WinoOut {
 // upper bound of the rows of a component plane for a batch of `rows` frames in n_utt utterances (scratch sizing)
 inline long wino_plane_rows(long rows, int n_utt) { return rows / kWinoM + n_utt + 1; }
 
-// one block: goff[u] = sum_{v<u} ceil(len_v / 4) (n_utt + 1 entries) and the plane offsets segp[j] = j * goff[n_utt], j <= n
+// one block: goff[u] = sum_{v<u} ceil(len_v / kWinoM) (n_utt + 1 entries) and the plane offsets segp[j] = j * goff[n_utt], j <= n
 __global__ void __launch_bounds__(64) wino_setup_kernel(const int* __restrict__ seg_off, int n_utt, int n, int* __restrict__ goff, int* __restrict__ segp) {
   const int lane = threadIdx.x;
   int base = 0;
