@@ -151,7 +151,9 @@ int stts_duration_to_alignment(void* stream, const int32_t* dur, int n_tokens, i
 /* Length regulator (train/utils.py:476-489 + models/speech_predictor.py:88-93): integer durations per token ->
  * time-major gather of the phoneme encoding at rate rep (1: mel frames, 4: vocoder frames).
  * dur [n_tok] int32 (device), tok_off [n_utt+1], frm_off [n_utt+1] (= rep * cumulative durations), both device.
- * enc [n_tok, ld_enc] -> out [frames, ld_out] columns [0, C). */
+ * enc [n_tok, ld_enc] -> out [frames, ld_out] columns [0, C).  Any number of tokens per utterance (the durations are
+ * scanned in chunks); limits elsewhere: the attention stages take at most 1024 keys per utterance (the reference's own
+ * limit is 510 tokens, train/dataloader.py:106-109) and stts_duration_to_alignment at most 1024 tokens. */
 int stts_length_regulate(stts_ctx* ctx, void* stream, int n_utt, const int32_t* dur, const int32_t* tok_off, const int32_t* frm_off,
                          int64_t n_frames, int rep, const float* enc, int ld_enc, int C, float* out, int ld_out, int32_t* src_row_ws);
 /* nn.Upsample(scale_factor=4, mode="linear") of pitch / energy (models/speech_predictor.py:64,89-90). */

@@ -105,6 +105,7 @@ size_t stts_frame_workspace_bytes(const stts_ctx* c, int64_t rows, int n_utt, in
   STTS_CHECK(c && (c->ready & (mask)) == (mask), "weights for this stage are not finalized (need components 0x%x, have 0x%x)", (mask), c ? c->ready : 0); \
   STTS_CHECK(n_utt > 0 && seg_off_host && seg_off_dev && seg_off_host[0] == 0, "bad utterance offsets"); \
   for (int _u = 0; _u < n_utt; ++_u) STTS_CHECK(seg_off_host[_u + 1] > seg_off_host[_u], "utterance %d is empty", _u); \
+  STTS_HIP(hipSetDevice(c->device));                                                 \
   Seg s{n_utt, seg_off_host, seg_off_dev};                                           \
   hipStream_t st = (hipStream_t)stream
 
@@ -166,8 +167,9 @@ int stts_frame_path(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off
 int stts_length_regulate(stts_ctx* c, void* stream, int n_utt, const int32_t* dur, const int32_t* tok_off, const int32_t* frm_off,
                          int64_t n_frames, int rep, const float* enc, int ld_enc, int C, float* out, int ld_out, int32_t* src_row_ws) {
   API_BEGIN
-  (void)c;
+  if (c) STTS_HIP(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
+  STTS_CHECK(dur && tok_off && frm_off && enc && out && src_row_ws && n_utt > 0 && n_frames >= 0 && rep >= 1, "length_regulate: bad argument");
   STTS_CHECK(C % 4 == 0 && ld_enc % 4 == 0 && ld_out % 4 == 0, "length_regulate: channel counts must be multiples of 4");
   hipLaunchKernelGGL(frame_token_map_kernel, dim3(n_utt), dim3(256), 0, st, dur, tok_off, frm_off, rep, src_row_ws);
   const long work = n_frames * (C / 4);
@@ -181,7 +183,7 @@ int stts_length_regulate(stts_ctx* c, void* stream, int n_utt, const int32_t* du
 int stts_upsample4(stts_ctx* c, void* stream, int n_utt, const int32_t* off_T_host, const int32_t* off_T, const int32_t* off_T4, const float* x,
                    float* y) {
   API_BEGIN
-  (void)c;
+  if (c) STTS_HIP(hipSetDevice(c->device));
   int ml = 0;
   for (int u = 0; u < n_utt; ++u) ml = std::max(ml, off_T_host[u + 1] - off_T_host[u]);
   hipLaunchKernelGGL(upsample4_kernel, dim3(ceil_div(4 * ml, 256), n_utt), dim3(256), 0, (hipStream_t)stream, x, off_T, off_T4, y);
@@ -219,6 +221,7 @@ int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, i
 // ------------------------------------------------------------------------------------------------ phoneme-rate stages
 #define PH_CHECK(mask)                                                               \
   STTS_CHECK(c && c->phoneme && (c->ready & (mask)) == (mask), "weights for this stage are not finalized (need components 0x%x, have 0x%x)", (mask), c ? c->ready : 0); \
+  STTS_HIP(hipSetDevice(c->device));                                                 \
   PhonemeModel& M = *static_cast<PhonemeModel*>(c->phoneme.get());                   \
   hipStream_t st = (hipStream_t)stream
 
@@ -238,7 +241,6 @@ int stts_text_encoder_forward(stts_ctx* c, void* stream, int which, int n_utt, c
   const int te_mask[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_TEXT};
   STTS_CHECK(which >= 0 && which < 3, "which must be 0 (duration), 1 (speech) or 2 (pitch/energy)");
   PH_CHECK(te_mask[which]);
-  STTS_CHECK(which >= 0 && which < 3, "which must be 0 (duration), 1 (speech) or 2 (pitch/energy)");
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   STTS_CHECK(ld_mu >= M.te[which].inter, "ld_mu too small");
   Seg s{n_utt, tok_off_host, tok_off_dev};
@@ -253,7 +255,6 @@ int stts_text_style_forward(stts_ctx* c, void* stream, int which, int n_utt, con
   const int se_mask[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_STYLE};
   STTS_CHECK(which >= 0 && which < 3, "which must be 0, 1 or 2");
   PH_CHECK(se_mask[which]);
-  STTS_CHECK(which >= 0 && which < 3, "which must be 0, 1 or 2");
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   STTS_CHECK(ldx % 32 == 0 && ldx >= M.se[which].inter, "style encoder input: ld must be a multiple of 32 covering inter_dim");
   Seg s{n_utt, tok_off_host, tok_off_dev};
@@ -344,6 +345,14 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   STTS_CHECK(precision >= 0 && precision <= 2, "precision must be STTS_PREC_F32, _BF16 or _F16");
   stts_ctx tmp;  // only for allocation bookkeeping
   tmp.prec = precision;
+  struct FreeAll {  // every exit path (including the early STTS_TRY / STTS_CHECK returns) waits for the stream and frees the temporaries
+    stts_ctx& t;
+    hipStream_t st;
+    ~FreeAll() {
+      (void)hipStreamSynchronize(st);
+      for (void* p : t.allocs) (void)hipFree(p);
+    }
+  } free_all{tmp, st};
   HostTensor w;
   w.shape = {cout, cin, k};
   w.data.assign(w_host, w_host + (size_t)cout * cin * k);
@@ -360,22 +369,18 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
     tmp.allocs.push_back(scratch);
     WinoScratch wz;
     wz.p = scratch;
-    int r = run_winograd(st, s, x, ldx, wc, y, ldy, act, nullptr, 0, 1.0f, wz);
-    hipError_t e = hipStreamSynchronize(st);
-    for (void* p : tmp.allocs) (void)hipFree(p);
-    STTS_HIP(e);
-    return r;
+    STTS_TRY(run_winograd(st, s, x, ldx, wc, y, ldy, act, nullptr, 0, 1.0f, wz));
+    STTS_HIP(hipStreamSynchronize(st));
+    return 0;
   }
   PackedConv pc;
   STTS_TRY(pack_rows(&tmp, w, bias_host ? &b : nullptr, plain_rows(cout), 0, cin, round_up(cin, 32), cout, &pc));
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, x, ldx, 0, pc, (k - 1) / 2, dil);
   a.N = cout; a.bias = pc.bias; a.Y = y; a.ldy = ldy; a.act = act;
-  int r = launch_conv_gemm(st, a, EPI_STORE, pc.npad, n_utt, s.max_len(), force_tile);
-  hipError_t e = hipStreamSynchronize(st);
-  for (void* p : tmp.allocs) (void)hipFree(p);
-  STTS_HIP(e);
-  return r;
+  STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, pc.npad, n_utt, s.max_len(), force_tile));
+  STTS_HIP(hipStreamSynchronize(st));
+  return 0;
   API_END
 }
 

@@ -393,31 +393,35 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
 }
 
 // durations [sum P] (int) per utterance -> frame->token row map at rate `rep` (rep=1: T frames, rep=4: T4 frames).
-// One block per utterance: inclusive scan of durations in LDS (P <= 1024), then each frame binary-searches.
-// tok_off: token offsets [n_utt+1]; frm_off: frame offsets at this rate [n_utt+1] (= rep * sum of durations).
+// One block per utterance, any number of tokens: the durations are scanned 256 at a time (LDS scan + running carry) and
+// every token writes its own rep * dur frames (at most 4 * 46), so there is no per-utterance token limit.
+// tok_off: token offsets [n_utt+1]; frm_off: frame offsets at this rate [n_utt+1] (= rep * sum of durations); frames
+// past rep * sum(dur) (inconsistent offsets) take the last token, nothing is written outside [frm_off[u], frm_off[u+1]).
 __global__ void __launch_bounds__(256) frame_token_map_kernel(const int* __restrict__ dur, const int* __restrict__ tok_off,
                                                               const int* __restrict__ frm_off, int rep, int* __restrict__ src_row) {
-  __shared__ int cum[1025];
-  const int u = blockIdx.x;
+  __shared__ int part[256];
+  const int u = blockIdx.x, tid = threadIdx.x;
   const int t0 = tok_off[u], P = tok_off[u + 1] - t0;
-  if (threadIdx.x == 0) {
-    int a = 0;
-    for (int i = 0; i < P; ++i) {
-      a += dur[t0 + i];
-      cum[i] = a;
-    }
-  }
-  __syncthreads();
   const int f0 = frm_off[u], nf = frm_off[u + 1] - f0;
-  for (int f = threadIdx.x; f < nf; f += 256) {
-    const int t = f / rep;  // frame at the duration rate
-    int lo = 0, hi = P - 1;
-    while (lo < hi) {  // first token with cum > t
-      const int mid = (lo + hi) >> 1;
-      if (cum[mid] > t) hi = mid; else lo = mid + 1;
+  int carry = 0;
+  for (int base = 0; base < P; base += 256) {
+    const int i = base + tid;
+    const int d = i < P ? max(dur[t0 + i], 0) : 0;
+    part[tid] = d;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
     }
-    src_row[f0 + f] = t0 + lo;
+    const int end = carry + part[tid];
+    const int lo = rep * (end - d), hi = min(rep * end, nf);
+    for (int f = lo; f < hi; ++f) src_row[f0 + f] = t0 + i;
+    carry += part[255];
+    __syncthreads();
   }
+  for (int f = rep * carry + tid; f < nf; f += 256) src_row[f0 + f] = t0 + max(P - 1, 0);
 }
 
 // Linear x4 upsample (align_corners=False) of a per-frame curve, per utterance.

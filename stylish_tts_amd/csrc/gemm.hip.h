@@ -398,7 +398,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         gX = n.X + n.xcol0;
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
-      if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
         seg_offsets();
       }
@@ -498,7 +497,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         gX = n.X + n.xcol0;
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
-      if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
       }
     };
@@ -731,23 +729,31 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
-// grow-only scratch for split-K partial sums, one buffer per launch stream (contractions issued on different streams
-// may run concurrently and must not share partials)
+// grow-only scratch for split-K partial sums, one buffer per (device, launch stream): contractions issued on different
+// streams may run concurrently and must not share partials, and the null stream exists on every device.
+// Growing allocates a NEW buffer and retires the old one (freed when the process ends its use of the library, never while
+// kernels that were given it may still be queued), so a larger batch after small ones costs one hipMalloc, not a
+// device-wide synchronisation.
 inline float* splitk_scratch(hipStream_t st, size_t bytes) {
   struct Buf {
     float* p = nullptr;
     size_t cap = 0;
   };
-  static std::map<hipStream_t, Buf> bufs;
+  static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+  static std::vector<void*> retired;
   static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
-  Buf& b = bufs[st];
+  Buf& b = bufs[{dev, st}];
   if (bytes > b.cap) {
-    if (b.p) {
+    if (b.p) retired.push_back(b.p);
+    if (retired.size() > 8) {  // bounded: reclaim the oldest once everything queued so far has drained
       (void)hipDeviceSynchronize();
-      (void)hipFree(b.p);
+      for (void* q : retired) (void)hipFree(q);
+      retired.clear();
     }
-    b.cap = bytes + bytes / 2;
+    b.cap = std::max(bytes + bytes / 2, (size_t)(8u << 20));
     if (hipMalloc(&b.p, b.cap) != hipSuccess) {
       b.p = nullptr;
       b.cap = 0;
@@ -784,15 +790,24 @@ inline GemmProfiler& gemm_profiler() {
   static GemmProfiler p;
   return p;
 }
+// 256 zero bytes on the CURRENT device (out-of-range operand fetches of the contraction kernels read them): one page per
+// device, created on first use, also under concurrent first calls from several host threads.
 inline const float* zero_page() {
-  static float* z = [] {  // initialised once, also under concurrent first calls from several host threads
+  constexpr int kMaxDev = 64;
+  static float* pages[kMaxDev] = {};
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDev) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pages[dev]) {
     float* p = nullptr;
     (void)hipMalloc(&p, 256);
     (void)hipMemset(p, 0, 256);
     (void)hipDeviceSynchronize();
-    return p;
-  }();
-  return z;
+    pages[dev] = p;
+  }
+  return pages[dev];
 }
 inline double gemm_algorithmic_flops(const GemmArgs& a) {
   double k = 0;

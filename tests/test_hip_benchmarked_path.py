@@ -1,0 +1,142 @@
+"""The code path bench.py times, pinned directly.
+
+At cfg2 (B = 8 x 3.0 s, R = 7 680 rows) the frame path takes other branches than the small parity cases do: the separate
+AdaIN apply pass instead of the folded affine (`run_adain_block`, rows > 4 096), Winograd conv1 in the decoder, the
+128-row / 16-wave contraction tiles and the 32-row fused WaveNet-layer kernel.  Here that very configuration is compared
+
+  (1) with the REFERENCE's own waveform: the `frame_path_3s` golden tiled to B = 8 (every utterance of the batch must
+      reproduce the golden's audio), with the atan2 branch ties adopted the reference's way between the STFT and the
+      vocoder stage (oracle.align_branch; the number of adopted bins and the raw, un-adopted error are printed);
+  (2) with the numpy oracle on utterance 0 of bench.py's own synthetic cfg2 inputs;
+
+and the fused entry point `stts_frame_path` (what bench.py calls) must be bit-identical to the staged calls.
+Tolerance: waveform sample-wise max-abs < 1e-3, intermediates 2e-4 of their max-abs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def hip(cfg, weights):
+    from stylish_tts_amd.runtime import HipModel
+
+    m = HipModel(cfg, 0)
+    m.load_weights({"speech_predictor": weights["speech_predictor"]}, which=7)
+    yield m
+    m.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def segs(lengths):
+    from stylish_tts_amd.runtime import Segments
+
+    return Segments(lengths, torch.device("cuda", 0))
+
+
+def adopt_reference_branches(phase_dev, spec_dev, g, B, T4):
+    """oracle.align_branch per utterance with the golden's recorded cut bins -> (device phase [B*T4, 1056], #adopted, #bad)."""
+    from oracle import stylish_oracle as O
+
+    ph = phase_dev.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
+    sp = spec_dev.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
+    hint = (g["cut_idx"].astype(np.int64), g["cut_phase"].astype(np.float32))
+    out = np.zeros((B * T4, 1056), np.float32)
+    adopted = bad = 0
+    for b in range(B):
+        fixed, nb = O.align_branch(ph[b : b + 1], hint, sp[b : b + 1], return_bad=True)
+        adopted += int((fixed != ph[b : b + 1]).sum())
+        bad += nb
+        out[b * T4 : (b + 1) * T4, :1025] = fixed[0].T
+    return dev(out), adopted, bad
+
+
+def test_cfg2_batch8_reproduces_the_reference_waveform(hip):
+    from stylish_tts_amd import synth
+
+    g = load_golden("frame_path_3s")
+    B, T4 = 8, 960
+    s = segs([T4] * B)
+    assert s.rows > 4096  # the large-batch branches (model.hip.h: run_adain_block `fold`, decoder Winograd conv1)
+    tile_rows = lambda a: dev(np.tile(a, (B, 1)))  # noqa: E731
+    asr = tile_rows(synth.normal("g3.asr", (1, 128, T4))[0].T)
+    pitch = dev(np.tile(synth.pitch_curve("g3.pitch", 1, T4)[0], B))
+    energy = dev(np.tile((synth.uniform("g3.energy", (1, T4)) * 2.0 + 2.0).astype(np.float32)[0], B))
+    style = dev(np.tile((synth.normal("g3.style", (1, 64)) * 0.7).astype(np.float32), (B, 1)))
+    nz = synth.path_noise("frame960", 1, T4)
+    pn = tile_rows(nz["prior_noise"][0].T)
+    sn = dev(np.tile(nz["src_noise"].reshape(-1), B))
+    ph0 = dev(nz["init_phase"].reshape(-1))
+
+    x = hip.decoder(s, asr, pitch, energy, style)
+    xs = x.cpu().numpy().reshape(B, T4, 512)
+    mel = hip.prior_flow(s, x, style, pn)
+    ms = mel.cpu().numpy().reshape(B, T4, 512)
+    for b in range(B):
+        for got, want, what in ((xs, g["x_probe"], "decoder"), (ms, g["mel_probe"], "mel")):
+            probe = got[b].T[None][:, ::64, ::16]
+            err = np.abs(probe - want).max()
+            assert err <= 2e-4 * np.abs(want).max(), (what, b, err)
+    spec, phase = hip.harmonic_stft(s, pitch, sn, ph0)
+    phase_ref, adopted, bad = adopt_reference_branches(phase, spec, g, B, T4)
+    assert bad == 0, f"{bad} hinted bins disagree with the reference by more than a branch choice"
+    audio = hip.vocoder(s, mel, style, spec, phase_ref).cpu().numpy().reshape(B, -1)
+    ref = g["audio"].reshape(-1)
+    errs = np.abs(audio - ref[None]).max(axis=1)
+    # the product path (no adoption): what `stts_frame_path` returns for the same inputs
+    fused = hip.frame_path(s, asr, pitch, energy, style, pn, sn, ph0)
+    staged_raw = hip.vocoder(s, mel, style, spec, phase)
+    assert torch.equal(fused, staged_raw)
+    raw = np.abs(fused.cpu().numpy().reshape(B, -1) - ref[None])
+    frames = raw.reshape(B, T4, 75).max(axis=2)  # per vocoder frame
+    late = frames[:, 64:].max()
+    print(f"\n[cfg2 B=8 vs reference golden] adopted atan2 branch bins: {adopted} of {B * 1025 * T4} "
+          f"({adopted // B} per utterance); waveform max-abs err with adoption {errs.max():.2e}; "
+          f"raw product path (no adoption): {raw.max():.2e} over all samples, {late:.2e} after frame 64, "
+          f"{(frames > 1e-3).sum() // B} of {T4} frames per utterance above 1e-3")
+    assert errs.max() < 1e-3, errs
+
+
+def test_bench_inputs_utterance0_matches_the_oracle(hip, weights):
+    """bench.py's own cfg2 batch: staged B = 8 run vs the oracle on utterance 0 (the oracle takes ~1-2 s for it)."""
+    from oracle import stylish_oracle as O
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert (bench.BATCH, bench.T4) == (8, 960)
+    inp = bench.synth_inputs(0, torch.device("cuda", 0))
+    B, T4 = bench.BATCH, bench.T4
+    s = segs([T4] * B)
+    x = hip.decoder(s, inp["asr"], inp["pitch"], inp["energy"], inp["style"])
+    mel = hip.prior_flow(s, x, inp["style"], inp["prior_noise"])
+    spec, phase = hip.harmonic_stft(s, inp["pitch"], inp["src_noise"], inp["init_phase"], batch_scope=True)
+    audio = hip.vocoder(s, mel, inp["style"], spec, phase)
+    fused = hip.frame_path(s, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
+                           batch_scope=True)
+    hip.check_status()
+    assert torch.equal(fused, audio)  # bench.py's call == the staged composition
+    h = inp["host"]
+    w = weights["speech_predictor"]
+    for u in (0,):
+        sl = slice(u * T4, (u + 1) * T4)
+        nz = dict(prior_noise=h["nz"]["prior_noise"][u : u + 1], src_noise=h["nz"]["src_noise"][u : u + 1], init_phase=h["nz"]["init_phase"])
+        a_in, p_in, e_in, s_in = h["asr"][sl].T[None].copy(), h["pitch"][sl][None], h["energy"][sl][None], h["style"][u : u + 1]
+        xd = O.decoder_forward(a_in, p_in, e_in, s_in, w)
+        ex = np.abs(x.cpu().numpy()[sl, :512].T - xd[0]).max() / np.abs(xd).max()
+        assert ex < 2e-4, ("decoder", ex)
+        hint = phase.cpu().numpy()[sl, :1025].T[None]
+        ref, _, _ = O.frame_path(a_in, p_in, e_in, s_in, nz, w, branch_hint=hint)
+        err = np.abs(audio.cpu().numpy()[75 * u * T4 : 75 * (u + 1) * T4] - ref[0, 0]).max()
+        print(f"\n[bench cfg2 inputs] utterance {u}: decoder rel err {ex:.2e}, waveform max-abs err vs oracle {err:.2e}")
+        assert err < 1e-3, err

@@ -81,19 +81,30 @@ def test_ragged_batch_is_per_utterance(hip):
 
 
 def test_duration_decode_both_branches(hip):
-    """DurationProcessor.prediction_to_duration on the golden logits (hard and soft branch)."""
+    """DurationProcessor.prediction_to_duration (train/utils.py:468-474) on the reference's golden logits, which reach
+    both the hard (argmax class < 7 frames) and the soft (expected value, rounded half-to-even) branch:
+    `stts_duration_decode` on the device, bit-equal to the reference's durations."""
     import ctypes as C
 
     from stylish_tts_amd import _lib
+    from stylish_tts_amd.runtime import _ptr, _stream
 
     g = load_golden("duration_processor")
-    lg = dev(g["logits"])
-    # reuse the duration stage's decode kernel through the stage API is not possible with foreign logits, so check the
-    # kernel semantics through a tiny duration run instead: decode is deterministic in logits -> compare via oracle table
-    from oracle import stylish_oracle as O
-
-    assert np.array_equal(O.prediction_to_duration(g["logits"]), g["duration"])
-    del lg, C, _lib
+    want = g["duration"].astype(np.int32)
+    hard = np.array([1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46])[g["logits"].argmax(-1)]
+    assert (hard < 7).any() and (hard >= 7).any(), "the fixture must reach both branches"
+    lg = dev(g["logits"].astype(np.float32))
+    dur = torch.full((lg.shape[0],), -1, dtype=torch.int32, device=lg.device)
+    _lib.check(_lib.load().stts_duration_decode(_stream(), _ptr(lg), lg.shape[1], lg.shape[0], _ptr(dur)))
+    assert np.array_equal(dur.cpu().numpy(), want)
+    # a wider leading dimension (the duration stage's own logits buffer may be padded)
+    wide = torch.zeros(lg.shape[0], 32, device=lg.device)
+    wide[:, :16] = lg
+    wide[:, 16:] = 1e4  # must be ignored
+    dur2 = torch.empty_like(dur)
+    _lib.check(_lib.load().stts_duration_decode(_stream(), _ptr(wide), 32, lg.shape[0], _ptr(dur2)))
+    assert torch.equal(dur, dur2)
+    del C
 
 
 def test_pitch_energy_golden(hip):
@@ -134,6 +145,21 @@ def test_length_regulator_and_upsample(hip):
     y = hip.upsample4(st, st4, dev(x)).cpu().numpy()
     ref = np.concatenate([O.upsample_linear4(x[None, :31])[0], O.upsample_linear4(x[None, 31:])[0]])
     close(y, ref, atol=1e-6, what="upsample x4")
+
+
+def test_length_regulator_has_no_token_limit(hip):
+    """An utterance of 1 500 tokens next to a short one through the C-ABI gather (the chunked duration scan of
+    frame_token_map_kernel; ADVICE r01: the LDS scan used to stop at 1 025 tokens)."""
+    from stylish_tts_amd import synth
+
+    P = [1500, 7]
+    durs = [1 + (np.arange(P[0]) * 7 % 5), synth.durations_for("lrbig.b", P[1], 20)]
+    T = [int(d.sum()) for d in durs]
+    sp, st4 = segs(P), segs([4 * t for t in T])
+    enc = synth.normal("lrbig.enc", (sum(P), 128))
+    out = hip.length_regulate(sp, st4, dev(np.concatenate(durs).astype(np.int32)), 4, dev(enc), 128).cpu().numpy()
+    want = np.repeat(enc, 4 * np.concatenate(durs), axis=0)
+    assert np.array_equal(out, want)
 
 
 def test_token_out_of_range_is_reported(hip):
