@@ -15,6 +15,7 @@
 #include "phoneme.hip.h"
 #include "wn_layer.hip.h"
 #include "wn_layer_small.hip.h"
+#include "wn_fused.hip.h"
 #include "winograd.hip.h"
 
 namespace stts {
@@ -74,8 +75,23 @@ struct AdainBlockW {
   StyleSlot n1, n2;
 };
 
+// fragment-order weights of one coupling layer for wn_fused_kernel (fp32 mode; wn_fused.hip.h)
+struct WnFusedW {
+  float* W1[2][4] = {};  // [0: F(2,5), 1: F(4,5)][WaveNet layer]: transformed in_layers planes
+  float* b1[4] = {};     // in_layers bias, natural order [256]
+  float* W2[4] = {};     // res_skip_layers
+  float* b2[4] = {};
+  float* W3 = nullptr;   // post: proj_mean | proj_logstd
+  float* b3m = nullptr;
+  float* b3s = nullptr;
+  float* W4 = nullptr;   // this layer's own `pre` (run by the tail of the layer before it in reverse order)
+  float* b4 = nullptr;
+  bool ready = false;
+};
+
 struct FlowLayerW {
   PackedConv pre, in[4], rs[4], proj;
+  WnFusedW fused;
   int cond_col0 = 0;
 };
 
@@ -352,6 +368,70 @@ inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout
   return 0;
 }
 
+// wn_fused_kernel operands of coupling layer `q` (prefix "...flow.flows.N."): every matrix in MFMA-fragment order
+// (wn_fused.hip.h: pack_fragments), the k = 5 conv as F(2,5) and F(4,5) planes G_j g computed in double.
+inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm, const HostTensor& pl, const HostTensor& pmb, const HostTensor& plb,
+                         WnFusedW* o) {
+  const int C = kWnC;
+  auto rows_of = [](const HostTensor& w) {  // [rows][K] (k = 1) as double
+    const int rows = (int)w.shape[0], K = (int)(w.data.size() / rows);
+    std::vector<std::vector<double>> r(rows, std::vector<double>(K));
+    for (int n = 0; n < rows; ++n)
+      for (int k = 0; k < K; ++k) r[n][k] = w.data[(size_t)n * K + k];
+    return r;
+  };
+  for (int i = 0; i < 4; ++i) {
+    HostTensor w, wr;
+    STTS_TRY(get_weight(c, q + "enc.in_layers." + std::to_string(i), &w));
+    STTS_GET(b, q + "enc.in_layers." + std::to_string(i) + ".bias");
+    STTS_CHECK(w.shape[0] == 2 * C && w.shape[1] == C && w.shape[2] == 5 && (int)b->data.size() == 2 * C, "wn_fused: in_layers.%d has an unexpected shape", i);
+    for (int v = 0; v < 2; ++v) {
+      WnFusedMats mt;
+      STTS_CHECK(wn_fused_matrices(v == 0 ? 2 : 4, &mt), "wn_fused: F(%d,5) matrices failed their self-check", v == 0 ? 2 : 4);
+      const int nc = mt.n;
+      std::vector<std::vector<double>> plane((size_t)nc * 2 * C, std::vector<double>(C));  // [component][output row][cin]
+      for (int j = 0; j < nc; ++j)
+        for (int n = 0; n < 2 * C; ++n)
+          for (int ci = 0; ci < C; ++ci) {
+            double acc = 0;
+            for (int k = 0; k < 5; ++k) acc += mt.G[j][k] * (double)w.data[((size_t)n * C + ci) * 5 + k];
+            plane[(size_t)j * 2 * C + n][ci] = acc;
+          }
+      // wave w, tile ((component j, half h), c): output rows h * 128 + 32 w + 16 c + col  (tanh rows 0..127 | sigmoid rows 128..255)
+      const std::vector<float> f = pack_fragments(kWnWaves, C / 16, nc * 4, [&](int wv, int t, int col) {
+        return plane[(size_t)(t >> 2) * 2 * C + ((t >> 1) & 1) * C + 32 * wv + 16 * (t & 1) + col].data();
+      });
+      STTS_TRY(dev_upload(c, f, &o->W1[v][i]));
+    }
+    STTS_TRY(dev_upload(c, b->data, &o->b1[i]));
+    STTS_TRY(get_weight(c, q + "enc.res_skip_layers." + std::to_string(i), &wr));
+    STTS_GET(br, q + "enc.res_skip_layers." + std::to_string(i) + ".bias");
+    const int n_rs = (int)wr.shape[0];
+    STTS_CHECK((n_rs == 2 * C || n_rs == C) && wr.shape[1] == C && (n_rs == C) == (i == 3), "wn_fused: res_skip_layers.%d has an unexpected shape", i);
+    const auto rr = rows_of(wr);
+    const int nct = n_rs / 16 / kWnWaves;  // column tiles per wave
+    const std::vector<float> f2 = pack_fragments(kWnWaves, C / 16, nct, [&](int wv, int t, int col) { return rr[(size_t)16 * nct * wv + 16 * t + col].data(); });
+    STTS_TRY(dev_upload(c, f2, &o->W2[i]));
+    STTS_TRY(dev_upload(c, br->data, &o->b2[i]));
+  }
+  STTS_CHECK(pm.shape[0] == C / 2 && pm.shape[1] == C && pl.shape[0] == C / 2, "wn_fused: proj has an unexpected shape");
+  const auto rm = rows_of(pm), rl = rows_of(pl);
+  const std::vector<float> f3 = pack_fragments(kWnWaves, C / 16, 2, [&](int wv, int t, int col) { return (t == 0 ? rm : rl)[(size_t)16 * wv + col].data(); });
+  STTS_TRY(dev_upload(c, f3, &o->W3));
+  STTS_TRY(dev_upload(c, pmb.data, &o->b3m));
+  STTS_TRY(dev_upload(c, plb.data, &o->b3s));
+  HostTensor wp;
+  STTS_TRY(get_weight(c, q + "pre", &wp));
+  STTS_GET(bp, q + "pre.bias");
+  STTS_CHECK(wp.shape[0] == C && wp.shape[1] == C / 2, "wn_fused: pre has an unexpected shape");
+  const auto rp = rows_of(wp);
+  const std::vector<float> f4 = pack_fragments(kWnWaves, C / 32, 2, [&](int wv, int t, int col) { return rp[(size_t)32 * wv + 16 * t + col].data(); });
+  STTS_TRY(dev_upload(c, f4, &o->W4));
+  STTS_TRY(dev_upload(c, bp->data, &o->b4));
+  o->ready = true;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalize: frame-rate path
 // ------------------------------------------------------------------------------------------------
@@ -431,6 +511,8 @@ inline int finalize_frame(stts_ctx* c, int which) {
       pc.shape[0] = 2 * half;
       pcb.data.insert(pcb.data.end(), plb->data.begin(), plb->data.end());
       STTS_TRY(pack_rows(c, pc, &pcb, paired_rows(half, 0, half), 0, fh, fh, half, &L.proj));
+      L.fused = WnFusedW();
+      if (c->prec == PREC_F32 && fh == kWnC && !getenv("STTS_NO_WN_FUSED")) STTS_TRY(pack_wn_fused(c, q, pm, pl, *pmb, *plb, &L.fused));
       HostTensor cw;
       STTS_TRY(get_weight(c, q + "enc.cond_layer", &cw));
       STTS_GET(cb, q + "enc.cond_layer.bias");
@@ -799,6 +881,62 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   return 0;
 }
 
+#ifdef STTS_WN_TRACE
+// diagnostics build only: per-wave phase stamps of the 32 fused WaveNet launches of one flow pass, averaged to stderr
+struct WnTrace {
+  long long* dev = nullptr;
+  long blocks[32] = {};
+  static constexpr long kMax = 1024;
+};
+inline WnTrace& wn_trace() {
+  static WnTrace t;
+  return t;
+}
+inline long long* wn_trace_buffer(int launch, long blocks) {
+  WnTrace& t = wn_trace();
+  if (!t.dev) (void)hipMalloc(&t.dev, 32 * WnTrace::kMax * 64 * sizeof(long long));
+  if (blocks > WnTrace::kMax) return nullptr;
+  t.blocks[launch] = blocks;
+  (void)hipMemsetAsync(t.dev + launch * WnTrace::kMax * 64, 0, blocks * 64 * sizeof(long long), 0);
+  return t.dev + launch * WnTrace::kMax * 64;
+}
+inline void wn_trace_report(hipStream_t st) {
+  WnTrace& t = wn_trace();
+  (void)hipStreamSynchronize(st);
+  static int calls = 0;
+  if (++calls % 8 != 0) return;
+  std::vector<long long> h(WnTrace::kMax * 64);
+  for (int kind = 0; kind < 2; ++kind) {  // plain layers, last layers
+    double ph[8][6] = {}, wall = 0, clk = 0;
+    long n = 0;
+    for (int l = 0; l < 32; ++l) {
+      if ((l % 4 == 3) != (kind == 1) || !t.blocks[l]) continue;
+      (void)hipMemcpy(h.data(), t.dev + l * WnTrace::kMax * 64, t.blocks[l] * 64 * sizeof(long long), hipMemcpyDeviceToHost);
+      for (long b = 0; b < t.blocks[l]; ++b) {
+        const long long* r0 = &h[64 * b];
+        if (!r0[5]) continue;
+        for (int wv = 0; wv < kWnWaves; ++wv) {
+          const long long* r = r0 + 8 * wv;
+          for (int i = 0; i < 6; ++i) ph[wv][i] += (double)(r[i] - r0[0]);  // cycles since wave 0 started
+        }
+        wall += (double)(r0[7] - r0[6]) * 10.0;  // ns
+        clk += (double)(r0[5] - r0[0]);
+        ++n;
+      }
+    }
+    if (!n) continue;
+    const double ghz = clk / wall;
+    fprintf(stderr, "[wn trace] %s layers: %ld blocks, wave 0: %.2f us per block at %.2f GHz; per wave, us since the block started: start | prologue end | phase-1 end | gate barrier | phase-2 end | end\n",
+            kind ? "last" : "plain", n, wall / n * 1e-3, ghz);
+    for (int wv = 0; wv < kWnWaves; ++wv) {
+      fprintf(stderr, "    wave %d:", wv);
+      for (int i = 0; i < 6; ++i) fprintf(stderr, " %6.2f", ph[wv][i] / n / ghz * 1e-3);
+      fprintf(stderr, "\n");
+    }
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // stage: PriorEncoder + reverse flow + post_flow (models/flow.py:311-315, :132-151, :196-218, :63-88)
 // ------------------------------------------------------------------------------------------------
@@ -807,11 +945,11 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   const stts_model_dims& d = c->d;
   const long R = s.rows();
   const int fh = d.dec_hidden / 4, half = fh / 2, ml = s.max_len();
-  float* z = ws.get<float>(R * fh);
-  float* hf = ws.get<float>(R * fh);
-  float* hf2 = ws.get<float>(R * fh);
-  float* outf = ws.get<float>(R * fh);
-  float* acts = ws.get<float>(R * fh);
+  // (kWnRowPad rows of slack: wn_fused_kernel reads whole 16-row tiles, also past the last utterance; never stored)
+  float* z = ws.get<float>((R + kWnRowPad) * fh);
+  float* hf = ws.get<float>((R + kWnRowPad) * fh);
+  float* hf2 = ws.get<float>((R + kWnRowPad) * fh);
+  float* outf = ws.get<float>((R + kWnRowPad) * fh);
   float* cond = ws.get<float>((size_t)s.n_utt * c->flow_style.ld());
   STTS_CHECK(ws.ok, "prior_flow_forward: workspace too small");
   STTS_TRY(run_style(st, c->flow_style, style, s.n_utt, cond));
@@ -828,14 +966,29 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   // ceil(blocks / 256) rounds of ~38 us (32 rows) or ~21 us (16 rows: half the MFMA chain, but the weight staging per
   // block is the same).  B = 8: 240 x 38 us beats 480 blocks = 2 x 21; B = 12: 720 blocks = 3 x 21 beats 360 = 2 x 38.
   bool rows16 = false;
+  int fused_m = 0;  // fp32: wn_fused_kernel with F(2,5) (32-row blocks) or F(4,5) (64-row blocks); 0 = the staged kernels
   if (c->prec == PREC_F32) {
-    long b32 = 0, b16 = 0;
+    long b64 = 0, b32 = 0, b16 = 0;
     for (int u = 0; u < s.n_utt; ++u) {
       const int len = s.host[u + 1] - s.host[u];
+      b64 += ceil_div(len, 64);
       b32 += ceil_div(len, 32);
       b16 += ceil_div(len, 16);
     }
     rows16 = ceil_div((int)b16, 256) * 21 < ceil_div((int)b32, 256) * 38;
+    if (c->flow[0].fused.ready) {
+      // wn_fused_kernel: one block per CU is resident, so a launch takes ceil(blocks / 256) rounds of ~kT2 us (F(2,5), 32-row
+      // blocks) or ~kT4 us (F(4,5), 64-row blocks); the staged 16-row kernel (one round = ~kT16 us) only wins while its
+      // blocks fit one round (B <= 4 at 3 s).  Measured (MI355X, tools/flow_bench.py): B = 8 28 us, B = 16 41 us (F(4,5)) vs
+      // 55 (F(2,5)), B = 64 150 us vs 209 per WaveNet layer; staged kernels 40 / - / 287.
+      const int force = getenv("STTS_WN_M") ? atoi(getenv("STTS_WN_M")) : 0;  // tests / tools: force a block shape
+      constexpr int kT16 = 22, kT2 = 28, kT4 = 41;
+      const int t16 = ceil_div((int)b16, 256) * kT16, t2 = ceil_div((int)b32, 256) * kT2, t4 = ceil_div((int)b64, 256) * kT4;
+      fused_m = t4 < t2 ? 4 : 2;
+      if (t16 <= std::min(t2, t4)) fused_m = 0;
+      rows16 = fused_m == 0;
+      if (force == 2 || force == 4) fused_m = force;
+    }
   }
   auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
   for (int f = 7; f >= 0; --f) {
@@ -877,8 +1030,32 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh) + extra);
       }
       const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
+      if (fused_m) {
+        auto launch = [&](auto mtag) {
+          constexpr int M = decltype(mtag)::value;
+          WnFusedArgs<M> fa;
+          memset(&fa, 0, sizeof(fa));
+          fa.Hin = hcur; fa.Hout = w.Hout; fa.Out = outf; fa.seg_off = s.dev;
+          fa.W1 = L.fused.W1[M == 2 ? 0 : 1][i]; fa.b1 = L.fused.b1[i]; fa.W2 = L.fused.W2[i]; fa.b2 = L.fused.b2[i];
+          fa.gate = cond; fa.ld_gate = w.ld_gate; fa.gcol0 = w.gcol0; fa.out_acc = w.out_acc; fa.tail = w.tail;
+          fa.W3 = L.fused.W3; fa.b3m = L.fused.b3m; fa.b3s = L.fused.b3s; fa.Z = w.Z; fa.ldz = w.ldz; fa.zcol0 = w.zcol0;
+          if (w.tail > 1) { fa.W4 = c->flow[f - 1].fused.W4; fa.b4 = c->flow[f - 1].fused.b4; fa.Hpre = w.Hpre; }
+          if (s.n_utt <= kWnSegInline) {
+            fa.n_inline = s.n_utt;
+            memcpy(fa.seg_inline, s.host, (s.n_utt + 1) * sizeof(int));
+          }
+          const dim3 fgrid(ceil_div(ml, 16 * M), s.n_utt);
+#ifdef STTS_WN_TRACE
+          fa.dbg = wn_trace_buffer((f * 4 + i), (long)fgrid.x * fgrid.y);
+#endif
+          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_kernel<M, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, fa);
+          else STTS_LAUNCH_TIMED((wn_fused_kernel<M, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, fa);
+        };
+        if (fused_m == 4) launch(std::integral_constant<int, 4>{});
+        else launch(std::integral_constant<int, 2>{});
+      }
       // small batches (fp32): 16-row blocks, twice the workgroups at half the chain length (wn_layer_small.hip.h)
-      if (rows16) STTS_LAUNCH_TIMED(wn_layer_rows16_kernel, dim3(ceil_div(ml, 16), s.n_utt), dim3(1024), st, e0, e1, w);
+      else if (rows16) STTS_LAUNCH_TIMED(wn_layer_rows16_kernel, dim3(ceil_div(ml, 16), s.n_utt), dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_BF16>, wgrid, dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_F16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F16>, wgrid, dim3(1024), st, e0, e1, w);
       else STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F32>, wgrid, dim3(1024), st, e0, e1, w);
@@ -886,6 +1063,9 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     }
     STTS_HIP(hipGetLastError());
   }
+#ifdef STTS_WN_TRACE
+  if (fused_m) wn_trace_report(st);
+#endif
   if (z_flow_out) STTS_HIP(hipMemcpyAsync(z_flow_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, z, fh, 0, c->post_flow);
@@ -1053,7 +1233,7 @@ inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int
   const stts_model_dims& d = c->d;
   const size_t f = sizeof(float);
   const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / kWinoM + n_utt + 1) * 8 * (608 + 512) * f + ((size_t)n_utt + 1024) * f;
-  const size_t flow = (size_t)R * 128 * 4 * f;
+  const size_t flow = ((size_t)R + kWnRowPad) * 128 * 4 * f;
   const size_t src = (size_t)R * (8 + kHop * f);
   // Winograd scratch (fp32 mode): 12 component planes of R/6 + n_utt + 1 rows x (768 in + 1024 out) for the output convs
   const size_t wino = ((size_t)R / kWinoM + n_utt + 1) * kWinoMaxN * (1056 + 1024) * f + ((size_t)n_utt + 1024) * f;

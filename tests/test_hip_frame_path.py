@@ -134,6 +134,35 @@ def test_prior_flow_golden(hip):
     close(cm(mel, 1, 512, 64), g["mel"], what="post_flow")
 
 
+@pytest.mark.parametrize("m", ["2", "4"])
+def test_prior_flow_fused_wavenet_kernel(hip, weights, m, monkeypatch):
+    """wn_fused_kernel (F(2,5) with 32-row blocks / F(4,5) with 64-row blocks; picked by batch size in production) forced
+    on small and ragged inputs: the reference golden, and per-utterance oracle runs for lengths that leave partial
+    blocks, one-row tails and utterances shorter than the conv's reach."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+
+    monkeypatch.setenv("STTS_WN_M", m)
+    g = load_golden("flow")
+    nz = synth.path_noise("frame64", 1, 64)
+    mel, zp, zf = hip.prior_flow(segs([64]), tm(g["x"]), dev(g["style"]), tm(nz["prior_noise"]), return_z=True)
+    close(cm(zf, 1, 128, 64), g["z_out"], what=f"reverse flow, F({m},5) blocks")
+    close(cm(mel, 1, 512, 64), g["mel"], what="post_flow")
+    lens = [65, 1, 33, 130, 2, 31, 64]
+    s = segs(lens)
+    w = weights["speech_predictor"]
+    xs = [synth.normal(f"wnf.x{i}", (1, 512, L)) for i, L in enumerate(lens)]
+    st = (synth.normal("wnf.s", (len(lens), 64)) * 0.7).astype(np.float32)
+    ns = [synth.normal(f"wnf.n{i}", (1, 128, L)) for i, L in enumerate(lens)]
+    cat = lambda parts: dev(np.concatenate([p[0].T for p in parts]))  # noqa: E731
+    mel, zp, zf = hip.prior_flow(s, cat(xs), dev(st), cat(ns), return_z=True)
+    zf = zf.cpu().numpy()
+    for i, L in enumerate(lens):
+        z, _, _ = O.prior_encoder(xs[i], ns[i], w)
+        ref = O.flow_reverse(z, st[i : i + 1, :, None], w)
+        close(zf[s.host[i] : s.host[i + 1], :128].T[None], ref, what=f"utterance {i} (len {L}), F({m},5) blocks")
+
+
 # ------------------------------------------------------------------------------------------------ source / STFT / vocoder
 def circ(a, b):
     return np.abs(np.angle(np.exp(1j * (np.asarray(a, np.float64) - np.asarray(b, np.float64)))))

@@ -96,8 +96,11 @@ def test_long_token_sequences_vs_oracle(hip, weights, cfg, P, T):
 
 
 # bf16 operand mode vs the oracle with the same rounding points: what remains is the fp32 summation order, which flips
-# individual operand roundings from layer to layer.  Bars are relative to each tensor's max-abs.
-CFG3_TOL = dict(text=1.5e-2, style=4e-3, prosody=2e-2, logits=2e-2, f0=3e-2, energy=6e-2, audio_rounded=8e-3, audio_fp32=1.2e-2)
+# individual operand roundings (2^-9 relative each) from layer to layer, so the distance to the rounded
+# oracle is of the same size as the distance to the fp32 one.  Bars are relative to each tensor's max-abs (audio: absolute,
+# |audio| < 1) and sit at about twice the measured values (MI355X, r02: text 1.4e-2, style 2.7e-3, prosody 8.6e-3,
+# logits 1.2e-2, f0 2.1e-2, energy 5.0e-2, audio 7.8e-3 vs the rounded and 1.0e-2 vs the fp32 oracle on ~14 s utterances).
+CFG3_TOL = dict(text=3e-2, style=6e-3, prosody=2e-2, logits=2.5e-2, f0=4e-2, energy=1e-1, audio_rounded=1.6e-2, audio_fp32=2e-2)
 
 
 def test_cfg3_chain_b64_bf16_vs_rounded_oracle(cfg, weights):
