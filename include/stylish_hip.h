@@ -173,6 +173,11 @@ int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, i
  * the summed ALGORITHMIC flops (2 * rows * cout * cin * taps, un-padded sizes). */
 int stts_profile_begin(void);
 int stts_profile_end(void* stream, int* launches, double* total_ms, double* total_flops);
+/* The same measurement per kernel, for every launch of the frame path (the bandwidth-bound kernels included): a JSON array
+ * [{"kernel", "kind": "contraction"|"other", "launches", "ms", "gflop" (algorithmic), "executed_gflop" (what the matrix
+ * cores execute: less for the Winograd forms), "mbytes" (algorithmic HBM bytes)}] summed over the launches
+ * since stts_profile_begin.  Ends the measurement like stts_profile_end. */
+int stts_profile_report(void* stream, char* json, size_t json_capacity);
 
 /* Single operators, exposed for parity tests (same kernels the stages use). */
 /* F.conv1d(stride 1, zero pad (k-1)/2*dil) on time-major rows; w is the reference layout [cout, cin, k] on the HOST. */

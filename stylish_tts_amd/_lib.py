@@ -74,6 +74,7 @@ SIGNATURES = {
     "stts_to_channel_major": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stts_profile_begin": (_I, []),
     "stts_profile_end": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "stts_profile_report": (_I, [_P, C.c_char_p, _SZ]),
     "stts_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _I]),
     "stts_op_conv1d": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I]),
     "stts_op_adain_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),

@@ -321,17 +321,58 @@ int stts_profile_end(void* stream, int* launches, double* total_ms, double* tota
   p.on = false;
   STTS_HIP(hipStreamSynchronize((hipStream_t)stream));
   double ms = 0, fl = 0;
-  for (size_t i = 0; i + 1 < p.used; i += 2) {
+  int n = 0;
+  for (size_t i = 0; i < p.recs.size() && 2 * i + 1 < p.used; ++i) {
+    if (p.recs[i].kind != 0) continue;  // the contraction kernels only (the other kernels: stts_profile_report)
     float t = 0;
-    STTS_HIP(hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]));
+    STTS_HIP(hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]));
     ms += t;
-    if (getenv("STTS_PROFILE_DUMP") && i / 2 < p.flops.size())  // per-launch list for tools/ (events include launch gaps)
-      fprintf(stderr, "launch %3zu  %8.1f us  %8.3f GFLOP  %6.1f TFLOP/s\n", i / 2, t * 1e3, p.flops[i / 2] * 1e-9, p.flops[i / 2] / (t * 1e-3) * 1e-12);
+    fl += p.recs[i].flops;
+    ++n;
   }
-  for (double f : p.flops) fl += f;
-  if (launches) *launches = (int)(p.used / 2);
+  if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
+  return 0;
+  API_END
+}
+
+int stts_profile_report(void* stream, char* json, size_t cap) {
+  API_BEGIN
+  STTS_CHECK(json && cap > 2, "bad argument");
+  GemmProfiler& p = gemm_profiler();
+  p.on = false;
+  STTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  struct Agg {
+    int kind = 0, n = 0;
+    double ms = 0, flops = 0, exec = 0, bytes = 0;
+  };
+  std::map<std::string, Agg> agg;
+  std::vector<std::string> order;
+  for (size_t i = 0; i < p.recs.size() && 2 * i + 1 < p.used; ++i) {
+    float t = 0;
+    STTS_HIP(hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]));
+    const ProfRec& r = p.recs[i];
+    if (!agg.count(r.name)) order.push_back(r.name);
+    Agg& g = agg[r.name];
+    g.kind = r.kind;
+    ++g.n;
+    g.ms += t;
+    g.flops += r.flops;
+    g.exec += r.exec_flops;
+    g.bytes += r.bytes;
+  }
+  std::string out = "[";
+  for (size_t k = 0; k < order.size(); ++k) {
+    const Agg& g = agg[order[k]];
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"kind\": \"%s\", \"launches\": %d, \"ms\": %.6f, \"gflop\": %.4f, \"executed_gflop\": %.4f, \"mbytes\": %.4f}",
+             k ? ", " : "", order[k].c_str(), g.kind == 0 ? "contraction" : "other", g.n, g.ms, g.flops * 1e-9, g.exec * 1e-9, g.bytes * 1e-6);
+    out += buf;
+  }
+  out += "]";
+  STTS_CHECK(out.size() + 1 <= cap, "profile report needs %zu bytes", out.size() + 1);
+  memcpy(json, out.c_str(), out.size() + 1);
   return 0;
   API_END
 }

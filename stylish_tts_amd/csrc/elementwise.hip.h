@@ -562,9 +562,10 @@ __global__ void seg_linear_kernel(int* __restrict__ out, int n, int step) {
 
 inline void launch_scale_weight(hipStream_t st, dim3 grid, int prec, const float* W, const float* gx, int ld_gx, const float* gamma, void* Wu, int npad,
                                 int kc) {
-  if (prec == PREC_BF16) hipLaunchKernelGGL(scale_weight_kernel<PREC_BF16>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);
-  else if (prec == PREC_F16) hipLaunchKernelGGL(scale_weight_kernel<PREC_F16>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);
-  else hipLaunchKernelGGL(scale_weight_kernel<PREC_F32>, grid, dim3(256), 0, st, W, gx, ld_gx, gamma, Wu, npad, kc);
+  const size_t bytes = (size_t)grid.y * npad * kc * (prec == PREC_F32 ? 4 : 2) + (size_t)npad * kc * 4;  // per-utterance copies out, W in
+  if (prec == PREC_BF16) STTS_LAUNCH_PROF("scale_weight_kernel", bytes, scale_weight_kernel<PREC_BF16>, grid, dim3(256), st, W, gx, ld_gx, gamma, Wu, npad, kc);
+  else if (prec == PREC_F16) STTS_LAUNCH_PROF("scale_weight_kernel", bytes, scale_weight_kernel<PREC_F16>, grid, dim3(256), st, W, gx, ld_gx, gamma, Wu, npad, kc);
+  else STTS_LAUNCH_PROF("scale_weight_kernel", bytes, scale_weight_kernel<PREC_F32>, grid, dim3(256), st, W, gx, ld_gx, gamma, Wu, npad, kc);
 }
 
 }  // namespace stts

@@ -767,15 +767,23 @@ inline float* splitk_scratch(hipStream_t st, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing of the contraction kernel with HIP events on the launch stream (bench.py's
 // roofline leg).  Off by default: when off the launcher records nothing.
+// One record per timed launch: kind 0 = a dense contraction (conv_gemm_f32, the fused WaveNet kernels, a whole Winograd-form
+// conv), kind 1 = everything else (bandwidth- / latency-bound kernels).  flops = ALGORITHMIC work (direct-conv flops,
+// un-padded), exec_flops = what the matrix cores execute (smaller for the Winograd forms), bytes = algorithmic HBM bytes.
+struct ProfRec {
+  const char* name;
+  int kind;
+  double flops, exec_flops, bytes;
+};
 struct GemmProfiler {
   bool on = false;
   std::vector<hipEvent_t> ev;  // pairs
-  std::vector<double> flops;
+  std::vector<ProfRec> recs;   // recs[i] belongs to the pair (ev[2 i], ev[2 i + 1])
   size_t used = 0;
   void begin() {
     on = true;
     used = 0;
-    flops.clear();
+    recs.clear();
   }
   hipEvent_t next() {
     if (used == ev.size()) {
@@ -785,6 +793,7 @@ struct GemmProfiler {
     }
     return ev[used++];
   }
+  void add(const char* name, int kind, double flops, double exec_flops, double bytes) { recs.push_back(ProfRec{name, kind, flops, exec_flops, bytes}); }
 };
 inline GemmProfiler& gemm_profiler() {
   static GemmProfiler p;
@@ -821,6 +830,20 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
   do {                                                                                            \
     if (e0) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, __VA_ARGS__);            \
     else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                             \
+  } while (0)
+
+// A bandwidth- / latency-bound kernel: timed like the contractions while the profiler is on (bench.py's `hbm_kernels` list),
+// a plain launch otherwise.  bytes = algorithmic HBM bytes of this launch.
+#define STTS_LAUNCH_PROF(name, bytes, kernel, grid, block, st, ...)                                \
+  do {                                                                                            \
+    stts::GemmProfiler& _p = stts::gemm_profiler();                                               \
+    if (_p.on) {                                                                                  \
+      hipEvent_t _e0 = _p.next(), _e1 = _p.next();                                                \
+      _p.add(name, 1, 0.0, 0.0, (double)(bytes));                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, _e0, _e1, 0, __VA_ARGS__);                \
+    } else {                                                                                      \
+      hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                \
+    }                                                                                             \
   } while (0)
 
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = PREC_F32>
@@ -970,7 +993,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     if (prof.on) {
       e0 = prof.next();
       e1 = prof.next();
-      prof.flops.push_back(flops * (double)ntiles / (double)all_rt);
+      prof.add("conv_gemm_f32", 0, flops * (double)ntiles / (double)all_rt, flops * (double)ntiles / (double)all_rt, 0.0);
     }
     auto dispatch = [&](auto prec_tag) {
       constexpr int PR = decltype(prec_tag)::value;
@@ -1009,7 +1032,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
         }
       }
       const long work = (long)(a.rows_total - row_first) * ((a.N + 3) / 4);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), 0, st, part, ksp, a.rows_total,
+      STTS_LAUNCH_PROF("splitk_reduce_kernel", (size_t)work * 4 * 4 * (ksp + 1), splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), st, part, ksp, a.rows_total,
                          row_first, npad, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha, a.Y, a.ldy, a.ycol0);
     }
   };

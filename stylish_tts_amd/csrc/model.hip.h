@@ -717,7 +717,8 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   if (timed) {
     prof.on = true;
     (void)hipEventRecord(prof.next(), st);
-    prof.flops.push_back(2.0 * (double)s.rows() * wc.planes.rows_real * wc.planes.cin_real * wc.mats.r);
+    prof.add("winograd_conv", 0, 2.0 * (double)s.rows() * wc.planes.rows_real * wc.planes.cin_real * wc.mats.r,
+             2.0 * (double)n * (double)pr * wc.planes.rows_real * wc.planes.cin_real, 0.0);
   }
   STTS_HIP(hipGetLastError());
   return 0;
@@ -731,7 +732,7 @@ inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, c
 }
 
 inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
-  hipLaunchKernelGGL(style_fc_kernel, dim3(ceil_div(t.J, 4)), dim3(256), 0, st, t.W, t.b, style, out, t.J, t.K, n_utt, t.K, t.ld());
+  STTS_LAUNCH_PROF("style_fc_kernel", (size_t)t.J * (t.K + n_utt) * 4, style_fc_kernel, dim3(ceil_div(t.J, 4)), dim3(256), st, t.W, t.b, style, out, t.J, t.K, n_utt, t.K, t.ld());
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -747,8 +748,8 @@ inline size_t adain_part_floats(const Seg& s, int C) { return (size_t)s.n_utt * 
 inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int C, float* Y, int ldy, const float* style_out, int ld_style,
                      int gcol0, int act, const float* alpha, float* part) {
   const int nchunk = ceil_div(s.max_len(), kStatChunk), ldp = round_up(C, 32);
-  hipLaunchKernelGGL(adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), 0, st, X, ldx, C, s.dev, part, ldp, nchunk);
-  hipLaunchKernelGGL(adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), 64), s.n_utt), dim3(256), 0, st, X, ldx, Y, ldy, C, s.dev,
+  STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk);
+  STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C + ldy) * 4, adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), 64), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
                      part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha);
   STTS_HIP(hipGetLastError());
   return 0;
@@ -769,8 +770,8 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   STTS_CHECK(ldx >= B.kcin, "adain block: input leading dimension %d < padded channels %d", ldx, B.kcin);
   auto affine = [&](const float* X, int ld, int C, int ld_aff, int gcol0, float* aff) {
     const int nchunk = ceil_div(ml, kStatChunk), ldp = round_up(C, 32);
-    hipLaunchKernelGGL(adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), 0, st, X, ld, C, s.dev, ss, ldp, nchunk);
-    hipLaunchKernelGGL(adain_affine_kernel, dim3(ceil_div(ld_aff, 64), s.n_utt), dim3(64), 0, st, ss, ldp, nchunk, s.dev, style_out, ld_style, gcol0, C,
+    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ld, C, s.dev, ss, ldp, nchunk);
+    STTS_LAUNCH_PROF("adain_affine_kernel", (size_t)s.n_utt * nchunk * 2 * ldp * 4, adain_affine_kernel, dim3(ceil_div(ld_aff, 64), s.n_utt), dim3(64), st, ss, ldp, nchunk, s.dev, style_out, ld_style, gcol0, C,
                        1e-5f, aff, ld_aff);
   };
   // norm1 -> LeakyReLU -> conv1
@@ -860,7 +861,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   fa.bf = c->front_bf; fa.bn = c->front_bn;
   fa.enc_in = enc_in; fa.ld_enc = ldenc; fa.xa = xa; fa.xb = xb; fa.ld_x = ldcat;
   fa.c_asr = d.inter_dim; fa.c_hidden = d.dec_hidden; fa.c_res = d.dec_residual;
-  hipLaunchKernelGGL(decoder_front_kernel, rows_grid(s, ldenc / 4), dim3(256), 0, st, fa, s.dev);
+  STTS_LAUNCH_PROF("decoder_front_kernel", (size_t)R * (d.inter_dim + 2 + ldenc + 2 * 4) * 4, decoder_front_kernel, rows_grid(s, ldenc / 4), dim3(256), st, fa, s.dev);
   // asr_res = wn-conv1x1(asr) into the residual columns of both concat buffers (decoder.py:54)
   for (float* dst : {xa, xb}) {
     GemmArgs a = gemm_args(s);
@@ -1027,7 +1028,9 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       if (prof.on) {
         e0 = prof.next();
         e1 = prof.next();
-        prof.flops.push_back(2.0 * (double)R * ((double)2 * fh * 5 * fh + (double)L.rs[i].N * fh) + extra);
+        const double rest = 2.0 * (double)R * (double)L.rs[i].N * fh + extra, conv = 2.0 * (double)R * 2 * fh * 5 * fh;
+        // the fused kernel executes F(M,5): M + 4 instead of 5 M products per channel and group of M rows
+        prof.add(fused_m ? "wn_fused_kernel" : "wn_layer_kernel", 0, conv + rest, (fused_m ? conv * (fused_m + 4) / (5.0 * fused_m) : conv) + rest, 0.0);
       }
       const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
       if (fused_m) {
@@ -1087,10 +1090,10 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
   for (int u = 0; u < s.n_utt; ++u)
     STTS_CHECK((long)(s.host[u + 1] - s.host[u]) * kHop > kNfft / 2, "utterance %d too short for reflect padding (%d frames; need > %d samples)", u,
                s.host[u + 1] - s.host[u], kNfft / 2);
-  hipLaunchKernelGGL(pcph_prep_kernel, dim3(s.n_utt), dim3(256), 0, st, pitch, s.dev, prefix, stats);
-  hipLaunchKernelGGL(pcph_kernel, dim3(std::min(1024, ceil_div(s.max_len() * kHop, 256)), s.n_utt), dim3(256), 0, st, pitch, s.dev, s.n_utt,
+  STTS_LAUNCH_PROF("pcph_prep_kernel", (size_t)R * 12, pcph_prep_kernel, dim3(s.n_utt), dim3(256), st, pitch, s.dev, prefix, stats);
+  STTS_LAUNCH_PROF("pcph_kernel", (size_t)R * kHop * 8, pcph_kernel, dim3(std::min(1024, ceil_div(s.max_len() * kHop, 256)), s.n_utt), dim3(256), st, pitch, s.dev, s.n_utt,
                      prefix, stats, noise, init_phase, batch_scope, sig, c->d_err);
-  hipLaunchKernelGGL(stft_kernel, dim3(s.max_len(), s.n_utt), dim3(256), 0, st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld);
+  STTS_LAUNCH_PROF("stft_kernel", (size_t)R * (kHop + 2 * kBins) * 4, stft_kernel, dim3(s.max_len(), s.n_utt), dim3(256), st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld);
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -1100,7 +1103,7 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
 // ------------------------------------------------------------------------------------------------
 inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows, const int* row_utt, float eps, int adaptive, int nout,
                      const LnOut& o0, const LnOut& o1, int act, const LnIn& in = LnIn{}) {
-  hipLaunchKernelGGL(row_layernorm_kernel, dim3((unsigned)ceil_div((int)n_rows, 4)), dim3(256), 0, st, X, ldx, C, (int)n_rows, row_utt, eps,
+  STTS_LAUNCH_PROF("row_layernorm_kernel", (size_t)n_rows * C * (1 + nout) * 4, row_layernorm_kernel, dim3((unsigned)ceil_div((int)n_rows, 4)), dim3(256), st, X, ldx, C, (int)n_rows, row_utt, eps,
                      adaptive, nout, o0, o1, act, in);
   STTS_HIP(hipGetLastError());
   return 0;
@@ -1148,7 +1151,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   STTS_CHECK(!logamp_out == !phase_out, "logamp_out and phase_out must be given together");
   const int lds = c->gen_style.ld();
   STTS_TRY(run_style(st, c->gen_style, style, s.n_utt, sty));
-  hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(ml, 256), s.n_utt), dim3(256), 0, st, s.dev, s.n_utt, row_utt);
+  STTS_LAUNCH_PROF("row_utt_kernel", (size_t)R * 4, row_utt_kernel, dim3(ceil_div(ml, 256), s.n_utt), dim3(256), st, s.dev, s.n_utt, row_utt);
   // projector over cat[mel, logamp_prior, phase_prior] as three K segments (generator.py:414)
   {
     GemmArgs a = gemm_args(s);
@@ -1162,7 +1165,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   float* nxt = xb;
   for (int i = 0; i < 4; ++i) {
     const ConvNextW& B = c->cnx[i];
-    hipLaunchKernelGGL((dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), 0, st, cur, h, dw, h, h, s.dev, B.dw_wt,
+    STTS_LAUNCH_PROF("dwconv_kernel", (size_t)R * h * 2 * 4, (dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), st, cur, h, dw, h, h, s.dev, B.dw_wt,
                        B.dw_b, B.K, (int)ACT_NONE);
     LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0}, o1{};
     STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE));
@@ -1171,7 +1174,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     a.N = inter; a.bias = B.pw1.bias; a.Y = U; a.ldy = inter; a.act = ACT_SILU;
     a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
-    hipLaunchKernelGGL(grn_gx_kernel, dim3(ceil_div(inter, 256), s.n_utt), dim3(256), 0, st, part, inter, ss_stride, s.dev, inter, gscale, inter);
+    STTS_LAUNCH_PROF("grn_gx_kernel", (size_t)s.n_utt * ss_stride * inter * 4, grn_gx_kernel, dim3(ceil_div(inter, 256), s.n_utt), dim3(256), st, part, inter, ss_stride, s.dev, inter, gscale, inter);
     launch_scale_weight(st, dim3(128, s.n_utt), B.pw2.prec, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, U, inter, 0, B.pw2);
@@ -1199,13 +1202,13 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     if (wino) STTS_TRY(run_winograd(st, s, headP, hc, c->wino_out[1], ph, ldl, ACT_NONE, nullptr, 0, 1.0f, wino));
     else STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
     const int kk = c->amp_out.ntaps;
-    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), 0, st, headA, hc, hc, s.dev, row_utt, c->nyq_w[0],
+    STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)R * (hc + 1) * 4, single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), st, headA, hc, hc, s.dev, row_utt, c->nyq_w[0],
                        c->nyq_b[0], kk, la, ldl, kBins - 1, (int)R);
-    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), 0, st, headP, hc, hc, s.dev, row_utt, c->nyq_w[1],
+    STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)R * (hc + 1) * 4, single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), st, headP, hc, hc, s.dev, row_utt, c->nyq_w[1],
                        c->nyq_b[1], kk, ph, ldl, kBins - 1, (int)R);
   }
-  hipLaunchKernelGGL(istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), 0, st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
-  hipLaunchKernelGGL(istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), 0, st, yw, s.dev, c->hann, audio);
+  STTS_LAUNCH_PROF("istft_frames_kernel", (size_t)R * 2 * kBins * 4, istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
+  STTS_LAUNCH_PROF("istft_ola_kernel", (size_t)R * kHop * 4, istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), st, yw, s.dev, c->hann, audio);
   STTS_HIP(hipGetLastError());
   return 0;
 }

@@ -69,3 +69,71 @@ def gather_waveforms(local_audio: torch.Tensor, local_ids: Sequence[int], sample
             out[i] = recv[r][off : off + int(sample_counts[i])]
             off += int(sample_counts[i])
     return out
+
+
+class WaveformCollector:
+    """Per-batch collection of the shards' waveforms on `dst` with EXACT sizes and no per-step allocation.
+
+    Built once for a batch layout (the per-utterance sample counts, global order): the deterministic partition gives every
+    rank's payload size, rank `dst` owns one flat receive buffer laid out rank after rank, and a step is one point-to-point
+    transfer per peer (``batch_isend_irecv``: over RCCL the peers write to `dst` over separate xGMI links; no ring, no
+    padding to the largest shard).  ``utterance(i)`` returns a view into the receive buffer."""
+
+    def __init__(self, sample_counts: Sequence[int], device, dst: int = 0):
+        self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
+        self.counts = [int(c) for c in sample_counts]
+        self.parts = partition_utterances(self.counts, self.world)
+        self.sizes = [int(sum(self.counts[i] for i in p)) for p in self.parts]
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+        self.local_ids = self.parts[self.rank]
+        self.recv = torch.empty(self.offsets[-1], dtype=torch.float32, device=device) if self.rank == dst else None
+        # gloo moves host memory only (CPU tests, single-GPU rehearsals of the N > 1 path): stage through pinned host buffers
+        self._host = None
+        if dist.get_backend() == "gloo" and torch.device(device).type == "cuda":
+            n = self.offsets[-1] if self.rank == dst else self.sizes[self.rank]
+            self._host = torch.empty(n, dtype=torch.float32).pin_memory()
+        self._where = {}
+        for r, p in enumerate(self.parts):
+            off = self.offsets[r]
+            for i in p:
+                self._where[i] = (off, self.counts[i])
+                off += self.counts[i]
+
+    def collect(self, local_audio: torch.Tensor):
+        """local_audio: this rank's utterances concatenated in ascending global id order (exactly sizes[rank] samples)."""
+        flat = local_audio.reshape(-1)
+        assert flat.numel() == self.sizes[self.rank], (flat.numel(), self.sizes[self.rank])
+        if self._host is not None:
+            return self._collect_via_host(flat)
+        if self.rank == self.dst:
+            self.recv[self.offsets[self.rank] : self.offsets[self.rank + 1]].copy_(flat)
+            ops = [dist.P2POp(dist.irecv, self.recv[self.offsets[r] : self.offsets[r + 1]], r) for r in range(self.world) if r != self.dst and self.sizes[r]]
+        else:
+            ops = [dist.P2POp(dist.isend, flat, self.dst)] if self.sizes[self.rank] else []
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return self.recv
+
+    def _collect_via_host(self, flat: torch.Tensor):
+        if self.rank == self.dst:
+            ops = [dist.P2POp(dist.irecv, self._host[self.offsets[r] : self.offsets[r + 1]], r) for r in range(self.world) if r != self.dst and self.sizes[r]]
+        else:
+            self._host.copy_(flat)
+            ops = [dist.P2POp(dist.isend, self._host, self.dst)] if self.sizes[self.rank] else []
+        for req in dist.batch_isend_irecv(ops) if ops else []:
+            req.wait()
+        if self.rank == self.dst:
+            self.recv.copy_(self._host, non_blocking=True)
+            self.recv[self.offsets[self.rank] : self.offsets[self.rank + 1]].copy_(flat)
+        return self.recv
+
+    def utterance(self, i: int) -> torch.Tensor:
+        off, n = self._where[i]
+        return self.recv[off : off + n]
+
+    def imbalance(self) -> float:
+        """max / mean of the per-rank payloads (1.0 = perfectly balanced)."""
+        return max(self.sizes) / (sum(self.sizes) / self.world) if sum(self.sizes) else 1.0

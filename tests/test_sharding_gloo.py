@@ -50,6 +50,14 @@ def _worker(rank, world, port, q):
         ok_g = True
         if rank == 0:
             ok_g = all(o.numel() == c and bool((o == float(i)).all()) for i, (o, c) in enumerate(zip(out, counts)))
+        # the pre-sized exact-size collector (what bench.py --workload cfg4 / cfg5 uses per step): two steps, same buffers
+        col = sharding.WaveformCollector(counts, torch.device("cpu"), dst=0)
+        assert col.local_ids == mine
+        for step in range(2):
+            col.collect(local + float(step))
+            if rank == 0:
+                ok_g = ok_g and all(col.utterance(i).numel() == c and bool((col.utterance(i) == float(i + step)).all()) for i, c in enumerate(counts))
+        ok_g = ok_g and col.imbalance() < 1.2 and col.recv is (col.recv if rank == 0 else None)
         q.put((rank, ok_b, ok_g))
     finally:
         dist.destroy_process_group()
