@@ -168,6 +168,20 @@ int stts_euler_step(void* stream, float* x, const float* v, float dt, int64_t n)
 int stts_to_time_major(void* stream, const float* x_bct, int B, int C, int T, float* y, int ldy);
 int stts_to_channel_major(void* stream, const float* x, int ldx, int B, int C, int T, float* y_bct);
 
+/* STFT.transform / STFT.inverse of models/stft.py:98-187: the conv1d / conv_transpose1d DFT-matrix STFT that the
+ * reference's ONNX export swaps into the generator (train/convert_to_onnx.py:31-36).  Not torch.stft: replicate padding, the
+ * Hann window at the start of the frame, magnitude sqrt(re^2 + im^2 + 1e-14) with re/mag and im/mag as outputs; the inverse
+ * sums the bins one-sided, scales by 1/n_fft and overlap-adds without window-envelope normalisation.  n_fft 2048 / window
+ * 1200 (model.yml), any hop.  Utterance u: F_u = frame_off[u+1] - frame_off[u] >= 2 frames <-> (F_u - 1) * hop samples,
+ * packed at sample offset hop * (frame_off[u] - u).  mag / x / y: time-major [frames, ld >= 1025] (pad columns zeroed by
+ * the transform).  The inverse needs frames * 1200 floats of workspace.
+ * (With the export's own arguments - hop 300 against the generator's hop 75 - the reference's generator raises at
+ * models/generator.py:414, tests/golden/onnx_stft_wiring_evidence.json, so these are pinned as a standalone module.) */
+int stts_conv_stft_transform(stts_ctx* ctx, void* stream, int n_utt, const int32_t* frame_off_host, const int32_t* frame_off_dev,
+                             const float* wave, int hop, float* mag, float* x, float* y, int ld);
+int stts_conv_stft_inverse(stts_ctx* ctx, void* stream, int n_utt, const int32_t* frame_off_host, const int32_t* frame_off_dev,
+                           const float* mag, const float* x, const float* y, int ld, int hop, float* wave_out, void* ws, size_t ws_bytes);
+
 /* Measurement hook (bench.py roofline leg): between begin and end every conv_gemm_f32 / wn_layer_kernel launch carries a
  * HIP start/stop event pair on its own stream.  end() synchronises and returns the launch count, the summed kernel time and
  * the summed ALGORITHMIC flops (2 * rows * cout * cin * taps, un-padded sizes). */

@@ -335,6 +335,43 @@ def istft(spec_mag, cx, sy, n_fft=2048, hop=75, win=1200):
     return (out[:, s:e] / env[s:e]).astype(F32)
 
 
+def conv_stft_transform(wave, n_fft=2048, hop=75, win=1200):
+    """STFT.transform (models/stft.py:98-139), the conv1d DFT-matrix STFT of the ONNX export: replicate ('edge') padding
+    of n_fft/2 samples, periodic Hann(win) at the START of the n_fft frame (zero-padded at the end, stft.py:39-46, not
+    centred like torch.stft), magnitude sqrt(re^2 + im^2 + 1e-14), and re/mag, im/mag.  wave [B,T] -> three [B,bins,frames]."""
+    pad = n_fft // 2
+    xp = np.pad(np.asarray(wave, F32), ((0, 0), (pad, pad)), mode="edge")
+    w = np.zeros(n_fft, F32)
+    w[:win] = hann_periodic(win)
+    frames = (xp.shape[1] - n_fft) // hop + 1
+    idx = hop * np.arange(frames)[:, None] + np.arange(n_fft)[None, :]
+    seg = (xp[:, idx] * w).astype(np.float64)  # [B, frames, n_fft]
+    spec = np.fft.rfft(seg, axis=-1).transpose(0, 2, 1)
+    re, im = spec.real, spec.imag
+    mag = np.sqrt(re * re + im * im + 1e-14)
+    return mag.astype(F32), (re / mag).astype(F32), (im / mag).astype(F32)
+
+
+def conv_stft_inverse(mag, x, y, n_fft=2048, hop=75, win=1200):
+    """STFT.inverse (models/stft.py:141-187): two conv_transpose1d with the windowed cos / sin matrices scaled by 1/n_fft
+    and summed as real - imag, i.e. per frame w[n]/N * Re sum_{k=0}^{N/2} X_k e^{+2 pi i k n/N} with a ONE-SIDED sum (the
+    reference does not double the inner bins, stft.py:73-77) and no window-envelope normalisation; centre trim n_fft/2."""
+    X = (np.asarray(mag, np.float64) * np.asarray(x, np.float64)) + 1j * (np.asarray(mag, np.float64) * np.asarray(y, np.float64))
+    B, bins, frames = X.shape
+    Xt = X.transpose(0, 2, 1)  # [B, frames, bins]
+    n = np.arange(n_fft)
+    full = np.fft.irfft(Xt, n=n_fft, axis=-1)  # Hermitian (doubled) sum / N
+    one_sided = 0.5 * full + 0.5 * (Xt[..., :1].real + np.where(n % 2 == 0, 1.0, -1.0) * Xt[..., -1:].real) / n_fft
+    w = np.zeros(n_fft, np.float64)
+    w[:win] = hann_periodic(win)
+    fr = one_sided * w
+    out = np.zeros((B, (frames - 1) * hop + n_fft), np.float64)
+    for f in range(frames):
+        out[:, f * hop : f * hop + n_fft] += fr[:, f]
+    pad = n_fft // 2
+    return out[:, None, pad:-pad].astype(F32)
+
+
 def grn(x_btc, gamma, beta):
     """GRN.forward (models/generator.py:496-499, models/conv_next.py:12-15): L2 over TIME (dim=1 of [B,T,C])."""
     gx = np.sqrt((x_btc.astype(np.float64) ** 2).sum(axis=1, keepdims=True))

@@ -72,6 +72,8 @@ SIGNATURES = {
     "stts_euler_step": (_I, [_P, _P, _P, C.c_float, C.c_int64]),
     "stts_to_time_major": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "stts_to_channel_major": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "stts_conv_stft_transform": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I]),
+    "stts_conv_stft_inverse": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ]),
     "stts_profile_begin": (_I, []),
     "stts_profile_end": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "stts_profile_report": (_I, [_P, C.c_char_p, _SZ]),

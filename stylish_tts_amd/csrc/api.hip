@@ -309,6 +309,65 @@ int stts_duration_to_alignment(void* stream, const int32_t* dur, int n_tokens, i
   API_END
 }
 
+// ------------------------------------------------------------------------------------------------ conv-form STFT (ONNX export)
+static int conv_stft_tables(stts_ctx* c) {
+  if (c->hann) return 0;
+  STTS_HIP(hipSetDevice(c->device));
+  std::vector<float> h(kWin);
+  for (int i = 0; i < kWin; ++i) h[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / kWin));
+  STTS_TRY(dev_upload(c, h, &c->hann));
+  std::vector<float2> tw(kNfft / 2);
+  std::vector<double2> tw64(kNfft / 2);
+  for (int i = 0; i < kNfft / 2; ++i) {
+    tw64[i] = make_double2(cos(2.0 * M_PI * i / kNfft), -sin(2.0 * M_PI * i / kNfft));
+    tw[i] = make_float2((float)tw64[i].x, (float)tw64[i].y);
+  }
+  STTS_TRY(dev_upload(c, tw, &c->twiddle));
+  STTS_TRY(dev_upload(c, tw64, &c->twiddle64));
+  return 0;
+}
+
+int stts_conv_stft_transform(stts_ctx* c, void* stream, int n_utt, const int32_t* frame_off_host, const int32_t* frame_off_dev, const float* wave,
+                             int hop, float* mag, float* x, float* y, int ld) {
+  API_BEGIN
+  STTS_CHECK(c && wave && mag && x && y && hop > 0 && ld >= kBins, "bad argument");
+  STTS_CHECK(c->d.n_fft == kNfft && c->d.win_length == kWin, "conv STFT: built for n_fft 2048 / win 1200 (model.yml)");
+  STTS_TRY(seg_ok(n_utt, frame_off_host, frame_off_dev));
+  STTS_TRY(conv_stft_tables(c));
+  int mf = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    STTS_CHECK(frame_off_host[u + 1] - frame_off_host[u] >= 2, "conv STFT: utterance %d needs at least 2 frames (hop samples)", u);
+    mf = std::max(mf, frame_off_host[u + 1] - frame_off_host[u]);
+  }
+  hipLaunchKernelGGL(conv_stft_kernel, dim3(mf, n_utt), dim3(256), 0, (hipStream_t)stream, wave, frame_off_dev, hop, c->hann, c->twiddle64, mag, x, y, ld);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+int stts_conv_stft_inverse(stts_ctx* c, void* stream, int n_utt, const int32_t* frame_off_host, const int32_t* frame_off_dev, const float* mag,
+                           const float* x, const float* y, int ld, int hop, float* wave_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  STTS_CHECK(c && wave_out && mag && x && y && hop > 0 && ld >= kBins, "bad argument");
+  STTS_CHECK(c->d.n_fft == kNfft && c->d.win_length == kWin, "conv STFT: built for n_fft 2048 / win 1200 (model.yml)");
+  STTS_TRY(seg_ok(n_utt, frame_off_host, frame_off_dev));
+  STTS_TRY(conv_stft_tables(c));
+  const long frames = frame_off_host[n_utt];
+  STTS_CHECK(ws && ws_bytes >= (size_t)frames * kWin * sizeof(float), "conv iSTFT: workspace needs frames * 1200 floats");
+  int mf = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    STTS_CHECK(frame_off_host[u + 1] - frame_off_host[u] >= 2, "conv iSTFT: utterance %d needs at least 2 frames", u);
+    mf = std::max(mf, frame_off_host[u + 1] - frame_off_host[u]);
+  }
+  float* yw = (float*)ws;
+  hipLaunchKernelGGL(conv_istft_frames_kernel, dim3(mf, n_utt), dim3(256), 0, (hipStream_t)stream, mag, x, y, ld, frame_off_dev, c->hann, c->twiddle, yw);
+  hipLaunchKernelGGL(conv_istft_ola_kernel, dim3(std::min(1024, ceil_div((mf - 1) * hop, 256)), n_utt), dim3(256), 0, (hipStream_t)stream, yw, frame_off_dev,
+                     hop, wave_out);
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
 // ------------------------------------------------------------------------------------------------ profiling
 int stts_profile_begin(void) {
   gemm_profiler().begin();

@@ -307,4 +307,124 @@ __global__ void __launch_bounds__(256) istft_ola_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conv-form STFT of the reference's ONNX export (models/stft.py:98-187): conv1d with the
+// windowed DFT matrices = a windowed DFT per frame, with these differences from torch.stft / torch.istft:
+//   * 'replicate' padding of n_fft/2 samples instead of reflect;
+//   * the periodic Hann(win) sits at the START of the n_fft frame (zero padded at the end, stft.py:39-46), not centred;
+//   * magnitude = sqrt(re^2 + im^2 + 1e-14) and the outputs are re/mag, im/mag (stft.py:131-139);
+//   * the inverse sums the bins ONE-SIDED (no doubling of the inner bins, stft.py:73-77), scales by 1/n_fft, windows again and
+//     overlap-adds with NO window-envelope normalisation, then trims n_fft/2 samples on both sides.
+// Utterance u has F_u = frame_off[u+1] - frame_off[u] frames and (F_u - 1) * hop samples starting at hop * (frame_off[u] - u).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_stft_kernel(const float* __restrict__ wave, const int* __restrict__ frame_off, int hop,
+                                                        const float* __restrict__ hann, const double2* __restrict__ twiddle, float* __restrict__ mag,
+                                                        float* __restrict__ xo, float* __restrict__ yo, int ld) {
+  constexpr int H = kNfft / 2;
+  __shared__ double2 A[H], Bf[H];
+  const int u = blockIdx.y, f = blockIdx.x;
+  const int lo = frame_off[u], nfr = frame_off[u + 1] - lo;
+  if (f >= nfr) return;
+  const long L = (long)(nfr - 1) * hop;
+  const float* x = wave + (long)hop * (lo - u);
+  for (int n = threadIdx.x; n < H; n += 256) {
+    double v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int p = 2 * n + e;
+      double val = 0.0;
+      if (p < kWin) {
+        long m = (long)f * hop - kNfft / 2 + p;
+        m = m < 0 ? 0 : (m >= L ? L - 1 : m);  // replicate
+        val = (double)(x[m] * hann[p]);
+      }
+      v[e] = val;
+    }
+    A[n] = make_double2(v[0], v[1]);
+  }
+  __syncthreads();
+  const double2* Z = fft_lds<double2, H, false>(A, Bf, twiddle, 2);
+  const long row = (long)(lo + f) * ld;
+  for (int k = threadIdx.x; k < ld; k += 256) {
+    float m = 0.f, cx = 0.f, cy = 0.f;
+    if (k < kBins) {
+      double re, im;
+      if (k == 0 || k == H) {
+        re = k == 0 ? Z[0].x + Z[0].y : Z[0].x - Z[0].y;
+        im = 0.0;
+      } else {
+        const double2 a = Z[k], b = Z[H - k];
+        const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+        const double orr = 0.5 * (a.y + b.y), oi = -0.5 * (a.x - b.x);
+        const double2 w = twiddle[k];
+        re = er + orr * w.x - oi * w.y;
+        im = ei + orr * w.y + oi * w.x;
+      }
+      const float fr = (float)re, fi = (float)im;
+      m = sqrtf(fr * fr + fi * fi + 1e-14f);
+      cx = fr / m;
+      cy = fi / m;
+    }
+    mag[row + k] = m;
+    xo[row + k] = cx;
+    yo[row + k] = cy;
+  }
+}
+
+// inverse, step 1: frame f -> its 1200 windowed samples  w[n] / N * Re sum_{k=0}^{N/2} X_k e^{+2 pi i k n / N},  X = mag (x + i y).
+// one-sided sum = (Hermitian inverse + (Re X_0 + (-1)^n Re X_{N/2}) / N) / 2, so the half-size transform of istft_frames_kernel serves.
+__global__ void __launch_bounds__(256) conv_istft_frames_kernel(const float* __restrict__ mag, const float* __restrict__ xi, const float* __restrict__ yi,
+                                                                int ld, const int* __restrict__ frame_off, const float* __restrict__ hann,
+                                                                const float2* __restrict__ twiddle, float* __restrict__ yw) {
+  constexpr int H = kNfft / 2;
+  __shared__ float2 Xs[H + 1], A[H], Bf[H], tw[H];
+  const int u = blockIdx.y, f = blockIdx.x;
+  const int lo = frame_off[u], nfr = frame_off[u + 1] - lo;
+  if (f >= nfr) return;
+  const long row = (long)(lo + f) * ld;
+  for (int i = threadIdx.x; i < H; i += 256) tw[i] = twiddle[i];
+  for (int k = threadIdx.x; k < kBins; k += 256) {
+    const float m = mag[row + k];
+    Xs[k] = make_float2(m * xi[row + k], (k == 0 || k == H) ? 0.f : m * yi[row + k]);
+  }
+  __syncthreads();
+  const float re0 = Xs[0].x, reN = Xs[H].x;
+  for (int k = threadIdx.x; k < H; k += 256) {
+    const float2 x = Xs[k], y = Xs[H - k];
+    const float er = 0.5f * (x.x + y.x), ei = 0.5f * (x.y - y.y);
+    const float dr = 0.5f * (x.x - y.x), di = 0.5f * (x.y + y.y);
+    const float2 w = tw[k];
+    const float orr = dr * w.x + di * w.y, oi = di * w.x - dr * w.y;
+    A[k] = make_float2(er - oi, ei + orr);
+  }
+  __syncthreads();
+  const float2* z = fft_lds<float2, H, true>(A, Bf, tw, 2);
+  float* o = yw + (long)(lo + f) * kWin;
+  for (int n = threadIdx.x; n < kWin; n += 256) {
+    const float2 v = z[n >> 1];
+    const float full = ((n & 1) ? v.y : v.x) * (1.0f / H);
+    o[n] = (0.5f * full + 0.5f * (re0 + ((n & 1) ? -reN : reN)) * (1.0f / kNfft)) * hann[n];
+  }
+}
+
+// inverse, step 2: overlap-add (gather form, deterministic) and centre trim: out sample s of utterance u is position t = s + n_fft/2
+// of the untrimmed signal; frame f contributes yw[f][t - hop f] while that index is in [0, 1200).
+__global__ void __launch_bounds__(256) conv_istft_ola_kernel(const float* __restrict__ yw, const int* __restrict__ frame_off, int hop, float* __restrict__ out) {
+  const int u = blockIdx.y;
+  const int lo = frame_off[u], nfr = frame_off[u + 1] - lo;
+  const long nsamp = (long)(nfr - 1) * hop;
+  const float* y = yw + (long)lo * kWin;
+  float* o = out + (long)hop * (lo - u);
+  for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < nsamp; s += (long)gridDim.x * 256) {
+    const long t = s + kNfft / 2;
+    long f_hi = t / hop;
+    if (f_hi > nfr - 1) f_hi = nfr - 1;
+    long f_lo = (t - (kWin - 1) + hop - 1) / hop;
+    if (t - (kWin - 1) < 0) f_lo = 0;
+    float acc = 0.f;
+    for (long f = f_lo; f <= f_hi; ++f) acc += y[f * kWin + (t - f * hop)];
+    o[s] = acc;
+  }
+}
+
 }  // namespace stts

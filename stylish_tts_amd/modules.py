@@ -355,6 +355,46 @@ class SpeechPredictor(HipModule):
         return DecoderPrediction(audio=[audio[75 * st4.host[b] : 75 * st4.host[b + 1]] for b in range(B)], magnitude=None, phase=None)
 
 
+class STFT(torch.nn.Module):
+    """models/stft.py:6-187: the conv-form STFT of the ONNX export, same constructor and transform() / inverse() signatures.
+    Only the model.yml geometry is built (filter_length 2048, window 1200, hann, center, replicate); any hop."""
+
+    def __init__(self, filter_length=800, hop_length=200, win_length=800, window="hann", center=True, pad_mode="replicate", cfg=None, engine=None):
+        super().__init__()
+        if (filter_length, win_length, window, center, pad_mode) != (2048, 1200, "hann", True, "replicate"):
+            raise NotImplementedError("the HIP conv-form STFT is built for filter_length 2048, win_length 1200, hann, center, replicate (model.yml)")
+        self.filter_length, self.hop_length, self.win_length, self.n_fft = filter_length, hop_length, win_length, filter_length
+        self.freq_bins = filter_length // 2 + 1
+        self._engine = engine
+        self._cfg = cfg
+
+    @property
+    def engine(self) -> HipModel:
+        if self._engine is None:
+            self._engine = get_engine(self._cfg, 0)
+        return self._engine
+
+    def transform(self, waveform: torch.Tensor):
+        """waveform [B, T] (T a multiple of the hop) -> magnitude, x, y [B, 1025, T / hop + 1] (stft.py:98-139)."""
+        eng, hop = self.engine, self.hop_length
+        B, T = waveform.shape
+        if T % hop:
+            raise ValueError("STFT.transform: the HIP path needs T to be a multiple of hop_length")
+        F = T // hop + 1
+        seg = Segments([F] * B, eng.device)
+        mag, x, y = eng.conv_stft_transform(seg, _f(waveform, eng.device).reshape(-1), hop)
+        return tuple(eng.to_channel_major(v, B, self.freq_bins, F) for v in (mag, x, y))
+
+    def inverse(self, magnitude: torch.Tensor, x: torch.Tensor, y: torch.Tensor, length=None):
+        """[B, 1025, F] x 3 -> waveform [B, 1, (F - 1) * hop] (stft.py:141-187)."""
+        eng, hop = self.engine, self.hop_length
+        B, _, F = magnitude.shape
+        seg = Segments([F] * B, eng.device)
+        tmaj = [eng.to_time_major(_f(v, eng.device), 1056) for v in (magnitude, x, y)]
+        wave = eng.conv_stft_inverse(seg, *tmaj, hop).reshape(B, 1, (F - 1) * hop)
+        return wave if length is None else wave[..., :length]
+
+
 class ExportModel(torch.nn.Module):
     """models/export_model.py:5-45: the inference composition (B = 1 in the reference: '1 1 l -> l')."""
 

@@ -195,6 +195,21 @@ class HipModel:
                                               kernel, _ptr(style), _ptr(y), channels, _ptr(ws), ws.numel()))
         return y
 
+    # ------------------------------------------------------------------ conv-form STFT of the ONNX export (models/stft.py)
+    def conv_stft_transform(self, seg_frames: Segments, wave: torch.Tensor, hop: int):
+        """wave: packed samples, utterance u has (frames_u - 1) * hop of them -> mag, x, y [frames, 1056] time-major."""
+        mag, x, y = (self._f32(seg_frames.rows, N_BINS_LD) for _ in range(3))
+        _lib.check(self.lib.stts_conv_stft_transform(self.ctx, _stream(), seg_frames.n, seg_frames.host_ptr, _ptr(seg_frames.dev), _ptr(wave), hop,
+                                                     _ptr(mag), _ptr(x), _ptr(y), N_BINS_LD))
+        return mag, x, y
+
+    def conv_stft_inverse(self, seg_frames: Segments, mag, x, y, hop: int):
+        out = self._f32((seg_frames.rows - seg_frames.n) * hop)
+        ws = self._f32(seg_frames.rows * 1200)
+        _lib.check(self.lib.stts_conv_stft_inverse(self.ctx, _stream(), seg_frames.n, seg_frames.host_ptr, _ptr(seg_frames.dev), _ptr(mag), _ptr(x), _ptr(y),
+                                                   mag.shape[1], hop, _ptr(out), _ptr(ws), ws.numel() * 4))
+        return out
+
     # ------------------------------------------------------------------ phoneme-rate stages (packed tokens)
     def _ph_ws(self, n_tok: int, n_frames: int, n_utt: int) -> torch.Tensor:
         """Grow-only phoneme-stage workspace, one per launch stream (stages on different streams may run concurrently)."""

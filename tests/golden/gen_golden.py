@@ -440,8 +440,55 @@ def cfm_golden():
     save("cfm_euler", **out)
 
 
+def conv_stft_golden():
+    """STFT.transform / STFT.inverse of models/stft.py:98-187 (the conv1d / conv_transpose1d DFT-matrix STFT the ONNX export
+    swaps into the generator), standalone, at the generator's own geometry (n_fft 2048, hop 75, window 1200), plus the
+    evidence for SURVEY 8a row 17: what the export wiring of train/convert_to_onnx.py:31-36 does to the generator."""
+    import json
+    import traceback
+
+    from stylish_tts.train.models.stft import STFT
+
+    st = STFT(filter_length=2048, hop_length=75, win_length=1200).eval()
+    wave = np.tanh(synth.normal("cstft.wave", (2, 1200)) * 0.5).astype(np.float32)
+    wave[1, 300:500] = 0.0  # a silent stretch: zero-magnitude bins (x, y are 0/sqrt(1e-14) there)
+    mag, x, y = st.transform(t(wave))
+    back = st.inverse(mag, x, y)
+    # inverse on an arbitrary (non-Hermitian-consistent) spectrum too: it is a plain linear map
+    m2 = np.abs(synth.normal("cstft.m2", (1, 1025, 9))).astype(np.float32)
+    ph = synth.normal("cstft.ph", (1, 1025, 9)).astype(np.float32) * 2.0
+    inv2 = st.inverse(t(m2), t(np.cos(ph)), t(np.sin(ph)))
+    save("conv_stft", wave=wave, mag=mag, x=x, y=y, back=back, m2=m2, x2=np.cos(ph), y2=np.sin(ph), inv2=inv2, torch_version=torch.__version__)
+
+    # --- row 17 evidence: the reference's own export wiring on its own generator
+    mc = load_model_config_yaml(open(os.path.join(REF_SRC, "stylish_tts/train/config/model.yml")))
+    cfg = load_model_config()
+    sp = load_synth(SpeechPredictor(mc), "speech_predictor", cfg)
+    sp.generator.stft = STFT(filter_length=mc.n_fft, hop_length=mc.hop_length, win_length=mc.win_length).eval()  # convert_to_onnx.py:31-36
+    T = 16
+    rec = dict(wiring="train/convert_to_onnx.py:31-36: generator.stft = STFT(filter_length=n_fft, hop_length=hop_length, win_length=win_length)",
+               n_fft=int(mc.n_fft), hop_length=int(mc.hop_length), win_length=int(mc.win_length), generator_hop=int(mc.hop_length) // 4, mel_frames=T,
+               torch_version=torch.__version__)
+    try:
+        out = sp.generator(mel=t(synth.normal("cstft.mel", (1, 512, 4 * T))), style=t(synth.normal("cstft.style", (1, 64))),
+                           pitch=t(synth.pitch_curve("cstft.pitch", 1, 4 * T)), energy=t(synth.uniform("cstft.en", (1, 4 * T))))
+        rec["outcome"] = "ran"
+        rec["audio_shape"] = list(out.audio.shape)
+    except Exception as e:  # noqa: BLE001
+        tb = traceback.extract_tb(e.__traceback__)
+        rec["outcome"] = "raised"
+        rec["exception"] = f"{type(e).__name__}: {e}"
+        # file:line:function of every frame (no source text)
+        rec["frames"] = [f"{os.path.relpath(f.filename, REF_SRC) if f.filename.startswith(REF_SRC) else os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in tb]
+    path = os.path.join(HERE, "onnx_stft_wiring_evidence.json")
+    json.dump(rec, open(path, "w"), indent=1)
+    print("  wrote onnx_stft_wiring_evidence.json:", rec["outcome"], rec.get("exception", ""))
+
+
 if __name__ == "__main__":
-    if "--only-cfm" in sys.argv:
+    if "--only-conv-stft" in sys.argv:
+        conv_stft_golden()
+    elif "--only-cfm" in sys.argv:
         cfm_golden()
     elif "--only-text" in sys.argv:
         _ = text_golden()
@@ -449,3 +496,4 @@ if __name__ == "__main__":
         main()
         text_golden()
         cfm_golden()
+        conv_stft_golden()

@@ -244,3 +244,82 @@ def test_synthesizer_soak_random_batches(mods):
         assert len(waves) == B
         for w, T in zip(waves, det["frames"]):
             assert w.numel() == 300 * T and bool(torch.isfinite(w).all()) and float(w.abs().max()) < 1.0
+
+
+def test_conv_stft_module_shim(cfg):
+    """modules.STFT == models/stft.py STFT (the conv-form STFT of the ONNX export) on the reference's golden: transform,
+    inverse of the transform, inverse of an arbitrary spectrum; plus a ragged packed call through the stage API."""
+    from stylish_tts_amd import modules
+    from stylish_tts_amd.runtime import Segments
+
+    g = load_golden("conv_stft")
+    st = modules.STFT(filter_length=2048, hop_length=75, win_length=1200, cfg=cfg)
+    mag, x, y = st.transform(dev(g["wave"]))
+    close(mag, g["mag"], rtol=2e-5, what="conv STFT magnitude")
+    strong = g["mag"] > 1e-3
+    assert np.abs(x.cpu().numpy() - g["x"])[strong].max() < 2e-3 and np.abs(y.cpu().numpy() - g["y"])[strong].max() < 2e-3
+    # an all-zero waveform: magnitude = sqrt(1e-14) and x = y = 0, like the reference's formula (stft.py:131-139)
+    mz, xz, yz = st.transform(torch.zeros(1, 300, device="cuda"))
+    assert float(mz.max()) == pytest.approx(1e-7, rel=1e-3) and float(xz.abs().max()) == 0.0 and float(yz.abs().max()) == 0.0
+    close(st.inverse(dev(g["mag"]), dev(g["x"]), dev(g["y"])), g["back"], rtol=2e-5, what="conv iSTFT of the reference transform")
+    close(st.inverse(dev(g["m2"]), dev(g["x2"]), dev(g["y2"])), g["inv2"], rtol=2e-5, what="conv iSTFT, arbitrary spectrum")
+    with pytest.raises(NotImplementedError):
+        modules.STFT(filter_length=800, hop_length=200, win_length=800)
+    # ragged: two utterances of different lengths in one packed call == each alone
+    eng = st.engine
+    w0, w1 = g["wave"][0, :900], g["wave"][1, :375]
+    seg = Segments([900 // 75 + 1, 375 // 75 + 1], eng.device)
+    m, xx, yy = eng.conv_stft_transform(seg, dev(np.concatenate([w0, w1])), 75)
+    m0 = st.transform(dev(w0[None]))[0]
+    m1 = st.transform(dev(w1[None]))[0]
+    assert torch.equal(m[: seg.host[1], :1025].t()[None], m0) and torch.equal(m[seg.host[1] :, :1025].t()[None], m1)
+    back = eng.conv_stft_inverse(seg, m, xx, yy, 75)
+    b0 = st.inverse(*st.transform(dev(w0[None])))
+    assert torch.equal(back[:900], b0.reshape(-1))
+
+
+def test_synthesizer_vs_the_oracle_chain(mods, weights, cfg):
+    """pipeline.Synthesizer (tokens -> waveforms, one packed pass) against the ORACLE's restatement of the reference chain
+    DurationPredictor -> DurationProcessor -> ExportModel: durations bit-equal, predicted pitch / energy
+    within 2e-2 Hz / 2e-3, and - teacher-forced with the engine's own pitch / energy, because the harmonic source integrates
+    pitch over the utterance - the waveform within 1e-3."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.pipeline import Synthesizer
+
+    eng = mods["speech_predictor"].engine
+    for m in mods.values():
+        m.engine
+    syn = Synthesizer(eng)
+    toks = [synth.tokens("syo.a", 1, 11, 178)[0], synth.tokens("syo.b", 1, 17, 178)[0]]
+    _, det = syn([t.tolist() for t in toks], return_details=True)
+    T = det["frames"]
+    R4 = 4 * sum(T)
+    noise = dict(prior_noise=dev(synth.normal("syo.pn", (R4, 128))), src_noise=dev(synth.normal("syo.sn", (R4 * 75,))),
+                 init_phase=dev(synth.uniform("syo.ph", (1,))))
+    waves, det = syn([t.tolist() for t in toks], noise=noise, return_details=True)
+    dur = det["durations"].cpu().numpy()
+    f0, en = det["pitch"].cpu().numpy(), det["energy"].cpu().numpy()
+    po, fo, f4 = 0, 0, 0
+    for i, tk in enumerate(toks):
+        P, Ti = len(tk), T[i]
+        lengths = np.array([P], np.int64)
+        lo = O.duration_predictor(tk[None], lengths, weights["duration_predictor"], cfg)
+        want = O.prediction_to_duration(lo[0]).astype(np.int32)
+        assert np.array_equal(dur[po : po + P], want), (i, dur[po : po + P], want)
+        al = O.duration_to_alignment(want)[None]
+        nz = dict(prior_noise=noise["prior_noise"][f4 : f4 + 4 * Ti].cpu().numpy().T[None].copy(),
+                  src_noise=noise["src_noise"][75 * f4 : 75 * (f4 + 4 * Ti)].cpu().numpy()[None, None], init_phase=noise["init_phase"].cpu().numpy().reshape(1, 1))
+        pe_enc, _, _ = O.text_encoder(tk[None], lengths, weights["pe_text_encoder"], cfg)
+        pe_sty = O.text_style_encoder(pe_enc, lengths, weights["pe_text_style_encoder"], cfg)
+        o_f0, o_n = O.pitch_energy_predictor(pe_enc, lengths, al, pe_sty, weights["pitch_energy_predictor"], cfg)
+        close(f0[fo : fo + Ti][None], o_f0, atol=2e-2, what=f"utt {i} predicted pitch [Hz]")
+        close(en[fo : fo + Ti][None], o_n, atol=2e-3, what=f"utt {i} predicted energy")
+        # teacher-forced waveform; the oracle adopts the engine's atan2 branch at the ill-conditioned bins (oracle.align_branch)
+        st4 = __import__("stylish_tts_amd.runtime", fromlist=["Segments"]).Segments([4 * Ti], eng.device)
+        p4 = eng.upsample4(__import__("stylish_tts_amd.runtime", fromlist=["Segments"]).Segments([Ti], eng.device), st4, det["pitch"][fo : fo + Ti].contiguous())
+        _, phase = eng.harmonic_stft(st4, p4, dev(nz["src_noise"].reshape(-1)), noise["init_phase"], batch_scope=False)
+        hint = phase.cpu().numpy()[:, :1025].T[None]
+        ref, _, _ = O.speech_predictor_forward(tk[None], lengths, al, f0[fo : fo + Ti][None], en[fo : fo + Ti][None], nz, weights["speech_predictor"], cfg, hint)
+        close(waves[i].cpu().numpy(), ref[0, 0], atol=1e-3, what=f"utt {i} waveform (teacher-forced pitch)")
+        po, fo, f4 = po + P, fo + Ti, f4 + 4 * Ti

@@ -171,3 +171,20 @@ def test_mrf_block():
     w = params.synth_state_dict(params.adaptive_generator_block_spec("", 128, 7, 64), 0, prefix="mrf.")
     y = O.adaptive_generator_block(g["x"], g["style"], w, "")
     close(y, g["y"], what="AdaptiveGeneratorBlock")
+
+
+def test_conv_stft_module():
+    """models/stft.py STFT (the ONNX export's conv-form STFT) standalone at the generator's geometry, and the recorded
+    outcome of the reference's own export wiring (it raises, so there is no ONNX-path waveform to pin)."""
+    import json
+    import os
+
+    g = load_golden("conv_stft")
+    mag, x, y = O.conv_stft_transform(g["wave"])
+    close(mag, g["mag"], rtol=2e-5, what="conv STFT magnitude")
+    strong = g["mag"] > 1e-3
+    assert np.abs(x - g["x"])[strong].max() < 2e-3 and np.abs(y - g["y"])[strong].max() < 2e-3
+    close(O.conv_stft_inverse(g["mag"], g["x"], g["y"]), g["back"], rtol=2e-5, what="conv iSTFT of the transform")
+    close(O.conv_stft_inverse(g["m2"], g["x2"], g["y2"]), g["inv2"], rtol=2e-5, what="conv iSTFT of an arbitrary spectrum")
+    ev = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "onnx_stft_wiring_evidence.json")))
+    assert ev["outcome"] == "raised" and ev["hop_length"] == 4 * ev["generator_hop"] and "generator.py" in ev["frames"][-1]
