@@ -444,7 +444,7 @@ inline bool wn_fused_matrices(int m, WnFusedMats* out) {
   const int r = 5, n = m + r - 1;
   if (m != 2 && m != 4) return false;
   const double all[7] = {0, 1, -1, 2, -0.5, -2, 0.5};
-  std::vector<double> pts(all, all + n - 1);
+  std::vector<double> pts(all, all + (n - 1));
   auto polymul = [](const std::vector<double>& x, const std::vector<double>& y) {
     std::vector<double> z(x.size() + y.size() - 1, 0.0);
     for (size_t i = 0; i < x.size(); ++i)
