@@ -221,8 +221,10 @@ def prior_encoder(x, noise, w: W, p: str = "prior_encoder."):
     return z.astype(F32), mean, logstd
 
 
-def wn_forward(x, g, w: W, p: str, hidden=128, n_layers=4, k=5):
-    """WN.forward (models/flow.py:63-88); x_mask is the scalar 1 on the inference path."""
+def wn_forward(x, g, w: W, p: str, hidden=None, n_layers=4, k=5):
+    """WN.forward (models/flow.py:63-88); x_mask is the scalar 1 on the inference path.  hidden = the flow width
+    (decoder.hidden_dim / 4, speech_predictor.py:36-58), read off the input when not given."""
+    hidden = x.shape[1] if hidden is None else hidden
     output = np.zeros_like(x)
     gc = linear(g.transpose(0, 2, 1), wn_legacy(w, p + "cond_layer"), w[p + "cond_layer.bias"], exact=True).transpose(0, 2, 1)  # [B, 2H*L, 1]
     for i in range(n_layers):

@@ -439,9 +439,14 @@ inline int finalize_frame(stts_ctx* c, int which) {
   const stts_model_dims& d = c->d;
   STTS_CHECK(d.n_fft == kNfft && d.win_length == kWin && d.hop_length / 4 == kHop && d.sample_rate == 24000,
              "this build is specialised for n_fft 2048 / win 1200 / hop 300 / 24 kHz (model.yml defaults)");
-  STTS_CHECK(d.style_dim == 64 && d.inter_dim == 128 && d.dec_hidden == 512 && d.dec_residual == 64 && d.gen_hidden == 512 &&
-                 d.gen_input == 512 && d.gen_inter == 1536,
-             "this build is specialised for the default model.yml channel sizes");
+  // channel sizes come from the model config (lib/config_loader.py:369-414); what the kernels need: 16-byte rows and column
+  // offsets (multiples of 32 for the concatenated widths) and the generator reading the decoder's width
+  STTS_CHECK(d.style_dim > 0 && d.style_dim % 4 == 0 && d.inter_dim > 0 && d.inter_dim % 4 == 0, "style_dim / inter_dim must be multiples of 4");
+  STTS_CHECK(d.dec_hidden > 0 && d.dec_hidden % 32 == 0 && d.dec_residual >= 0 && d.dec_residual % 2 == 0,
+             "decoder.hidden_dim must be a multiple of 32 (the flow runs on hidden_dim / 4 channels split in two halves), residual_dim even");
+  STTS_CHECK(d.gen_input == d.dec_hidden, "generator.input_dim (%d) must equal decoder.hidden_dim (%d): post_flow feeds the generator", d.gen_input, d.dec_hidden);
+  STTS_CHECK(d.gen_hidden > 0 && d.gen_hidden % 32 == 0 && d.gen_inter > 0 && d.gen_inter % 32 == 0,
+             "generator.hidden_dim / conv_intermediate_dim must be multiples of 32");
   const std::string sp = "speech_predictor.";
   // tables
   if (!c->hann) {
@@ -458,6 +463,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
   // decoder (models/decoder.py:6-45)
   if (which & STTS_W_DECODER) {
     c->dec_style = StyleTable();
+    c->dec_style.K = d.style_dim;
     HostTensor wf, wn;
     STTS_TRY(get_weight(c, sp + "decoder.F0_conv", &wf));
     STTS_TRY(get_weight(c, sp + "decoder.N_conv", &wn));
@@ -479,6 +485,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
   // prior + flow + post_flow (models/flow.py, models/speech_predictor.py:36-62)
   if (which & STTS_W_FLOW) {
     c->flow_style = StyleTable();
+    c->flow_style.K = d.style_dim;
     const int fh = d.dec_hidden / 4, half = fh / 2;
     HostTensor wm, wl;
     STTS_TRY(get_weight(c, sp + "prior_encoder.proj_mean", &wm));
@@ -524,6 +531,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
   // generator (models/generator.py:340-438)
   if (which & STTS_W_GENERATOR) {
     c->gen_style = StyleTable();
+    c->gen_style.K = d.style_dim;
     const std::string g = sp + "generator.";
     const int h = d.gen_hidden, hp = h / 2;
     STTS_TRY(pack_plain(c, g + "amp_prior_conv", true, 0, kBins, &c->amp_prior));
@@ -598,11 +606,31 @@ inline int finalize_frame(stts_ctx* c, int which) {
 // ------------------------------------------------------------------------------------------------
 // workspace bump allocator (caller-owned memory)
 // ------------------------------------------------------------------------------------------------
+// Workspace sizing by dry run (stts_frame_workspace_bytes): the stages carve their buffers from an Arena over a fake address
+// range, stop before their first launch and report how far they got - so the bound is what the stages really request,
+// for any model dims, instead of a hand-derived closed form.
+struct DryRun {
+  bool on = false;
+  size_t peak = 0;
+};
+inline DryRun& dry_run() {
+  static thread_local DryRun d;
+  return d;
+}
+#define STTS_DRY_RETURN(arena)                                                   \
+  do {                                                                            \
+    if (stts::dry_run().on) {                                                     \
+      stts::dry_run().peak = std::max(stts::dry_run().peak, (arena).offset0 + (arena).used); \
+      return 0;                                                                   \
+    }                                                                             \
+  } while (0)
+
 struct Arena {
   char* base;
   size_t cap, used = 0;
+  size_t offset0 = 0;  // where this arena starts inside the caller's workspace (dry-run accounting)
   bool ok = true;
-  Arena(void* p, size_t n) : base((char*)p), cap(n) {}
+  Arena(void* p, size_t n, size_t off0 = 0) : base((char*)p), cap(n), offset0(off0) {}
   template <typename T>
   T* get(size_t count) {
     const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
@@ -854,6 +882,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   WinoScratch wino;
   if (R > 4096 && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
+  STTS_DRY_RETURN(ws);
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
   FrontArgs fa;
   fa.asr = asr; fa.ld_asr = ld_asr; fa.pitch = pitch; fa.energy = energy;
@@ -951,8 +980,13 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   float* hf = ws.get<float>((R + kWnRowPad) * fh);
   float* hf2 = ws.get<float>((R + kWnRowPad) * fh);
   float* outf = ws.get<float>((R + kWnRowPad) * fh);
+  // the fused WaveNet kernels are built for 128 flow channels (decoder.hidden_dim 512); other widths run every layer as
+  // two contractions (gate epilogue, then res/skip split-accumulate) and need the gated activations in memory
+  const bool generic = fh != kWnC;
+  float* actsg = generic ? ws.get<float>(R * fh) : nullptr;
   float* cond = ws.get<float>((size_t)s.n_utt * c->flow_style.ld());
   STTS_CHECK(ws.ok, "prior_flow_forward: workspace too small");
+  STTS_DRY_RETURN(ws);
   STTS_TRY(run_style(st, c->flow_style, style, s.n_utt, cond));
   {
     GemmArgs a = gemm_args(s);
@@ -995,6 +1029,33 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   for (int f = 7; f >= 0; --f) {
     const FlowLayerW& L = c->flow[f];
     const int p = f & 1;
+    if (generic) {
+      // ResidualCouplingLayer.forward(reverse) as plain contractions (flow.py:196-218, WN :63-88): pre -> 4 x {conv k5 with
+      // the gate in its epilogue, res/skip with the h / out split in its epilogue} -> post with the coupling in its epilogue
+      GemmArgs a = gemm_args(s);
+      set_seg(a, 0, z, fh, p * half, L.pre);
+      a.N = fh; a.bias = L.pre.bias; a.Y = hf; a.ldy = fh;
+      STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, L.pre.npad, s.n_utt, ml));
+      for (int i = 0; i < 4; ++i) {
+        GemmArgs g = gemm_args(s);
+        set_seg(g, 0, hf, fh, 0, L.in[i]);
+        g.N = fh; g.bias = L.in[i].bias; g.Y = actsg; g.ldy = fh;
+        g.gate = cond; g.ld_gate = c->flow_style.ld(); g.gcol0 = L.cond_col0 + i * 2 * fh; g.gC = fh;
+        STTS_TRY(launch_conv_gemm(st, g, EPI_GATE, L.in[i].npad, s.n_utt, ml));
+        GemmArgs r = gemm_args(s);
+        set_seg(r, 0, actsg, fh, 0, L.rs[i]);
+        r.N = L.rs[i].N; r.bias = L.rs[i].bias;
+        r.D0 = hf; r.ldd0 = fh; r.acc0 = 1;                 // h += rs[:fh]   (every row tile reads only its own rows of `acts`)
+        r.D1 = outf; r.ldd1 = fh; r.acc1 = i > 0;           // out (+)= rs[fh:] ; last layer: all of rs
+        r.nsplit = L.rs[i].N == 2 * fh ? fh : 0;
+        STTS_TRY(launch_conv_gemm(st, r, EPI_SPLIT_ACC, L.rs[i].npad, s.n_utt, ml));
+      }
+      GemmArgs q = gemm_args(s);
+      set_seg(q, 0, outf, fh, 0, L.proj);
+      q.N = half; q.bias = L.proj.bias; q.Z = z; q.ldz = fh; q.zcol0 = (1 - p) * half;
+      STTS_TRY(launch_conv_gemm(st, q, EPI_COUPLE, L.proj.npad, s.n_utt, ml));
+      continue;
+    }
     if (f == 7) {  // later blocks get their `pre` from the tail of the previous block's last WaveNet launch
       GemmArgs a = gemm_args(s);
       set_seg(a, 0, z, fh, p * half, L.pre);
@@ -1087,6 +1148,7 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
   float* stats = ws.get<float>(2 * s.n_utt);
   float* sig = prior_out ? prior_out : ws.get<float>(R * kHop);
   STTS_CHECK(ws.ok, "harmonic_stft: workspace too small");
+  STTS_DRY_RETURN(ws);
   for (int u = 0; u < s.n_utt; ++u)
     STTS_CHECK((long)(s.host[u + 1] - s.host[u]) * kHop > kNfft / 2, "utterance %d too short for reflect padding (%d frames; need > %d samples)", u,
                s.host[u + 1] - s.host[u], kNfft / 2);
@@ -1148,6 +1210,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   WinoScratch wino;
   if (c->wino_out[0].ready && c->wino_out[1].ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->wino_out[0]));
   STTS_CHECK(ws.ok, "vocoder: workspace too small");
+  STTS_DRY_RETURN(ws);
   STTS_CHECK(!logamp_out == !phase_out, "logamp_out and phase_out must be given together");
   const int lds = c->gen_style.ld();
   STTS_TRY(run_style(st, c->gen_style, style, s.n_utt, sty));
@@ -1221,29 +1284,18 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* headP = ws.get<float>(R * hc);
   STTS_CHECK(ws.ok, "vocoder_forward: workspace too small");
   {
-    Arena tmp(ws.base + ws.used, ws.cap - ws.used);  // released again before vocoder_body carves its own buffers
+    Arena tmp(ws.base + ws.used, ws.cap - ws.used, ws.offset0 + ws.used);  // released again before vocoder_body carves its own buffers
     WinoScratch wino;
     if (c->wino_prior[0].ready) wino.p = tmp.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
     STTS_CHECK(tmp.ok, "vocoder_forward: workspace too small");
-    STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, &wino));
-    STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, &wino));
+    if (dry_run().on) {
+      dry_run().peak = std::max(dry_run().peak, tmp.offset0 + tmp.used);
+    } else {
+      STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, &wino));
+      STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, &wino));
+    }
   }
   return vocoder_body(c, st, s, mel, ld_mel, style, headA, headP, audio, logamp_out, phase_out, ld_lp, ws);
-}
-
-inline size_t frame_workspace_bytes(const stts_ctx* c, int64_t R, int n_utt, int max_len) {
-  // closed form upper bound: the largest stage (vocoder) + the stage hand-off buffers + per-buffer alignment slack
-  const stts_model_dims& d = c->d;
-  const size_t f = sizeof(float);
-  const size_t dec = (size_t)R * (160 + 608 * 3 + 512 * 2) * f + ((size_t)R / kWinoM + n_utt + 1) * 8 * (608 + 512) * f + ((size_t)n_utt + 1024) * f;
-  const size_t flow = ((size_t)R + kWnRowPad) * 128 * 4 * f;
-  const size_t src = (size_t)R * (8 + kHop * f);
-  // Winograd scratch (fp32 mode): 12 component planes of R/6 + n_utt + 1 rows x (768 in + 1024 out) for the output convs
-  const size_t wino = ((size_t)R / kWinoM + n_utt + 1) * kWinoMaxN * (1056 + 1024) * f + ((size_t)n_utt + 1024) * f;
-  const size_t voc = (size_t)R * ((512 + 256) * 2 + 512 * 4 + d.gen_inter + 1056 * 2 + 1 + kWin) * f + (size_t)n_utt * kWin * f + wino;
-  const size_t per_utt = (size_t)n_utt * ((size_t)(ceil_div(max_len, 128) * 4 + 1) * d.gen_inter + 512 * (size_t)d.gen_inter + 32768) * f;
-  const size_t handoff = (size_t)R * (512 + 512 + 1056 * 2 + 768 * 2 + kHop + 2) * f;
-  return std::max(std::max(dec, flow), std::max(src, voc)) + handoff + per_utt + (size_t)64 * 4096;
 }
 
 inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* asr, int ld_asr, const float* pitch, const float* energy,
@@ -1251,36 +1303,75 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
                       float* audio, void* wsp, size_t ws_bytes) {
   const long R = s.rows();
   Arena top(wsp, ws_bytes);
-  const int ldh = round_up(kBins, 32), hc = c->d.gen_hidden + c->d.gen_hidden / 2;
-  float* x = top.get<float>(R * 512);
-  float* mel = top.get<float>(R * 512);
+  const int ldh = round_up(kBins, 32), hc = c->d.gen_hidden + c->d.gen_hidden / 2, dh = c->d.dec_hidden;
+  float* x = top.get<float>(R * dh);
+  float* mel = top.get<float>(R * dh);
   float* hs = top.get<float>(R * ldh);
   float* hp = top.get<float>(R * ldh);
   float* headA = top.get<float>(R * hc);
   float* headP = top.get<float>(R * hc);
-  char* side_ws = top.get<char>((size_t)R * (sizeof(double) + kHop * sizeof(float)) + 4096 + 8 * s.n_utt);
-  STTS_CHECK(top.ok, "frame_path: workspace too small");
   const size_t side_bytes = (size_t)R * (sizeof(double) + kHop * sizeof(float)) + 4096 + 8 * s.n_utt;
+  const size_t side_off = top.used;
+  char* side_ws = top.get<char>(side_bytes);
+  STTS_CHECK(top.ok, "frame_path: workspace too small");
   const size_t mark = top.used;
   auto stage = [&]() {
-    Arena a((char*)wsp + mark, ws_bytes - mark);
+    Arena a((char*)wsp + mark, ws_bytes - mark, mark);
     return a;
   };
   // Measured: running the (independent) source -> STFT -> prior-conv chain on side streams next to decoder/flow gains
   // < 1 % at B = 8 (7.51 vs 7.57 ms/step): the decoder GEMMs already fill the chip, so the stages stay on one stream.
-  { Arena a(side_ws, side_bytes); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a)); }
+  { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a)); }
   {
     Arena a = stage();
     WinoScratch wino;
     if (c->wino_prior[0].ready) wino.p = a.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
     STTS_CHECK(a.ok, "frame_path: workspace too small");
-    STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino));
-    STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino));
+    if (dry_run().on) {
+      dry_run().peak = std::max(dry_run().peak, a.offset0 + a.used);
+    } else {
+      STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino));
+      STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino));
+    }
   }
-  { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, 512, a)); }
-  { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, 512, style, prior_noise, mel, 512, nullptr, nullptr, a)); }
-  { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, 512, style, headA, headP, audio, nullptr, nullptr, 0, a)); }
+  { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
+  { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a)); }
+  { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, dh, style, headA, headP, audio, nullptr, nullptr, 0, a)); }
   return 0;
+}
+
+// Bytes of caller-owned workspace that every frame-rate entry point accepts for a batch of `R` rows in `n_utt` utterances,
+// the longest `max_len` rows: a DRY RUN of the stages themselves over a fake address range (each carves its buffers, records
+// how far it got and returns before its first launch), so the bound follows the model dims and whatever the stages really
+// request.  Buffer sizes depend on the batch only through (R, n_utt, max_len); weights must be finalized (which convs have a
+// Winograd form decides their scratch).
+inline size_t frame_workspace_bytes(const stts_ctx* cc, int64_t R, int n_utt, int max_len) {
+  stts_ctx* c = const_cast<stts_ctx*>(cc);
+  if (R <= 0 || n_utt <= 0 || max_len <= 0) return 0;
+  max_len = (int)std::min<int64_t>(max_len, R);
+  std::vector<int> off(n_utt + 1, 0);  // any lengths with this total, count and maximum
+  long rest = R - max_len;
+  off[1] = max_len;
+  for (int u = 1; u < n_utt; ++u) {
+    const long len = std::max<long>(1, std::min<long>(max_len, rest - (n_utt - 1 - u)));
+    off[u + 1] = off[u] + (int)len;
+    rest -= len;
+  }
+  Seg s{n_utt, off.data(), nullptr};
+  DryRun& d = dry_run();
+  d.on = true;
+  d.peak = 0;
+  char* fake = reinterpret_cast<char*>((uintptr_t)1 << 20);
+  const size_t cap = (size_t)1 << 46;
+  (void)frame_path(c, nullptr, s, nullptr, c->d.inter_dim, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, fake, cap);
+  {  // the staged entry points start their carving at offset 0; vocoder_forward with its own head buffers is the largest of them
+    Arena a(fake, cap);
+    (void)vocoder_forward(c, nullptr, s, nullptr, c->d.dec_hidden, nullptr, nullptr, nullptr, round_up(kBins, 32), nullptr, nullptr, nullptr, 0, a);
+    Arena b(fake, cap);
+    (void)decoder_forward(c, nullptr, s, nullptr, c->d.inter_dim, nullptr, nullptr, nullptr, nullptr, c->d.dec_hidden, b);
+  }
+  d.on = false;
+  return d.peak + 4096;
 }
 
 }  // namespace stts

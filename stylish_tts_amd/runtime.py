@@ -114,19 +114,21 @@ class HipModel:
 
     # ------------------------------------------------------------------ stages (time-major tensors)
     def decoder(self, seg: Segments, asr, pitch, energy, style):
-        x = self._f32(seg.rows, 512)
+        dh = self.cfg.decoder.hidden_dim
+        x = self._f32(seg.rows, dh)
         ws = self.workspace(seg)
         _lib.check(self.lib.stts_decoder_forward(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(asr), asr.shape[1], _ptr(pitch),
-                                                 _ptr(energy), _ptr(style), _ptr(x), 512, _ptr(ws), ws.numel()))
+                                                 _ptr(energy), _ptr(style), _ptr(x), dh, _ptr(ws), ws.numel()))
         return x
 
     def prior_flow(self, seg: Segments, x, style, prior_noise, return_z=False):
-        mel = self._f32(seg.rows, 512)
-        zp = self._f32(seg.rows, 128) if return_z else None
-        zf = self._f32(seg.rows, 128) if return_z else None
+        dh = self.cfg.decoder.hidden_dim
+        mel = self._f32(seg.rows, dh)
+        zp = self._f32(seg.rows, dh // 4) if return_z else None
+        zf = self._f32(seg.rows, dh // 4) if return_z else None
         ws = self.workspace(seg)
         _lib.check(self.lib.stts_prior_flow_forward(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(x), x.shape[1], _ptr(style),
-                                                    _ptr(prior_noise), _ptr(mel), 512, _ptr(zp), _ptr(zf), _ptr(ws), ws.numel()))
+                                                    _ptr(prior_noise), _ptr(mel), dh, _ptr(zp), _ptr(zf), _ptr(ws), ws.numel()))
         return (mel, zp, zf) if return_z else mel
 
     def harmonic_stft(self, seg: Segments, pitch, src_noise, init_phase, batch_scope=True, return_signal=False):

@@ -440,6 +440,45 @@ def cfm_golden():
     save("cfm_euler", **out)
 
 
+NARROW = {"decoder": {"hidden_dim": 384, "residual_dim": 32}, "generator": {"input_dim": 384, "hidden_dim": 384, "conv_intermediate_dim": 1152}}
+
+
+def narrow_golden():
+    """A model.yml that is NOT the default one (decoder / generator width 384 instead of 512, residual 32, ConvNeXt
+    intermediate 1152: the flow then runs on 96 channels): the reference's SpeechPredictor built from that config, decoder ->
+    prior / flow -> vocoder on a 64-frame utterance.  Pins that the build follows lib/config_loader.py:369-414 rather than
+    one set of constants."""
+    import copy
+
+    import yaml
+
+    raw = yaml.safe_load(open(os.path.join(REF_SRC, "stylish_tts/train/config/model.yml")))
+    ours = copy.deepcopy(dict(load_model_config()))
+    for sec, kv in NARROW.items():
+        raw[sec].update(kv)
+        ours[sec] = dict(ours[sec], **kv)
+    import io
+
+    mc = load_model_config_yaml(io.StringIO(yaml.safe_dump(raw)))
+    cfg = load_model_config(ours)
+    sp = load_synth(SpeechPredictor(mc), "speech_predictor", cfg)
+    CutTape.stft = sp.generator.stft
+    T4 = 64
+    asr = t(synth.normal("nw.asr", (1, 128, T4)))
+    pitch = t(synth.pitch_curve("nw.pitch", 1, T4))
+    energy = t(synth.uniform("nw.energy", (1, T4)) * 2.0 + 2.0)
+    style = t(synth.normal("nw.style", (1, 64)) * 0.7)
+    nz = synth.path_noise("narrow64", 1, T4, flow_dim=NARROW["decoder"]["hidden_dim"] // 4)
+    with Replay(randn=[nz["src_noise"]], rand=[nz["init_phase"]], randn_like=[nz["prior_noise"]]), CutTape() as cut:
+        xd, _ = sp.decoder(asr, pitch, energy, style)
+        z, mean, logstd = sp.prior_encoder(xd)
+        z2, _, _ = sp.flow(z, mean, logstd, 1, style.unsqueeze(-1), reverse=True)
+        mel = sp.post_flow(z2.mT).mT
+        pred = sp.generator(mel=mel, style=style, pitch=pitch, energy=energy)
+    save("frame_path_narrow", x=xd, z=z, z_out=z2, mel=mel, audio=pred.audio, config_overrides=np.frombuffer(yaml.safe_dump(NARROW).encode(), np.uint8),
+         torch_version=torch.__version__, **cut.hints())
+
+
 def conv_stft_golden():
     """STFT.transform / STFT.inverse of models/stft.py:98-187 (the conv1d / conv_transpose1d DFT-matrix STFT the ONNX export
     swaps into the generator), standalone, at the generator's own geometry (n_fft 2048, hop 75, window 1200), plus the
@@ -488,6 +527,8 @@ def conv_stft_golden():
 if __name__ == "__main__":
     if "--only-conv-stft" in sys.argv:
         conv_stft_golden()
+    elif "--only-narrow" in sys.argv:
+        narrow_golden()
     elif "--only-cfm" in sys.argv:
         cfm_golden()
     elif "--only-text" in sys.argv:
@@ -497,3 +538,4 @@ if __name__ == "__main__":
         text_golden()
         cfm_golden()
         conv_stft_golden()
+        narrow_golden()

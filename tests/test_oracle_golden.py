@@ -188,3 +188,39 @@ def test_conv_stft_module():
     close(O.conv_stft_inverse(g["m2"], g["x2"], g["y2"]), g["inv2"], rtol=2e-5, what="conv iSTFT of an arbitrary spectrum")
     ev = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "onnx_stft_wiring_evidence.json")))
     assert ev["outcome"] == "raised" and ev["hop_length"] == 4 * ev["generator_hop"] and "generator.py" in ev["frames"][-1]
+
+
+def narrow_cfg():
+    """The non-default model.yml of tests/golden/gen_golden.py:narrow_golden (overrides recorded in the fixture)."""
+    import copy
+
+    import yaml
+    from stylish_tts_amd.config import load_model_config
+
+    g = load_golden("frame_path_narrow")
+    over = yaml.safe_load(bytes(g["config_overrides"]).decode())
+    base = copy.deepcopy(dict(load_model_config()))
+    for sec, kv in over.items():
+        base[sec] = dict(base[sec], **kv)
+    return load_model_config(base), g
+
+
+def test_frame_path_non_default_widths():
+    """decoder / generator width 384, residual 32, ConvNeXt intermediate 1152 (flow on 96 channels): the oracle follows the
+    config through the weights' shapes."""
+    cfg, g = narrow_cfg()
+    w = params.synth_state_dict(params.module_spec("speech_predictor", cfg), 0, prefix="speech_predictor.")
+    T4 = 64
+    asr = synth.normal("nw.asr", (1, 128, T4))
+    pitch = synth.pitch_curve("nw.pitch", 1, T4)
+    energy = (synth.uniform("nw.energy", (1, T4)) * 2.0 + 2.0).astype(np.float32)
+    style = (synth.normal("nw.style", (1, 64)) * 0.7).astype(np.float32)
+    nz = synth.path_noise("narrow64", 1, T4, flow_dim=cfg.decoder.hidden_dim // 4)
+    x = O.decoder_forward(asr, pitch, energy, style, w)
+    close(x, g["x"], what="Decoder (hidden 384)")
+    z, _, _ = O.prior_encoder(g["x"], nz["prior_noise"], w)
+    close(z, g["z"], what="PriorEncoder (96 channels)")
+    close(O.flow_reverse(g["z"], style[:, :, None], w), g["z_out"], what="reverse flow (96 channels)")
+    close(O.post_flow(g["z_out"], w), g["mel"], what="post_flow")
+    audio, _, _ = O.frame_path(asr, pitch, energy, style, nz, w, hint(g))
+    close(audio, g["audio"], atol=1e-3, what="waveform (non-default widths)")
