@@ -449,14 +449,16 @@ def align_branch(phase, hint, spec=None, return_bad=False):
 
 def _output_conv(x, wt, b, padding):
     """The 768 -> 1025 head convs.  In the 16-bit operand modes the HIP path runs bins 0..1023 on the matrix cores and
-    the Nyquist bin as an fp32 dot product (single_channel_conv_kernel), so only the former see rounded operands."""
+    the Nyquist bin as an fp32 dot product (single_channel_conv_kernel) over the same 16-bit activation rows: its
+    activations are rounded, its weights are not."""
     if OPERAND_ROUND is None:
         return conv1d(x, wt, b, padding=padding)
     lo = conv1d(x, wt[:-1], b[:-1], padding=padding)
     mode = OPERAND_ROUND
+    xr = round_operand(x)
     try:
         _set_round(None)
-        hi = conv1d(x, wt[-1:], b[-1:], padding=padding)
+        hi = conv1d(xr, wt[-1:], b[-1:], padding=padding)
     finally:
         _set_round(mode)
     return np.concatenate([lo, hi], axis=1)

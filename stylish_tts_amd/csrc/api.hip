@@ -478,6 +478,16 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, x, ldx, 0, pc, (k - 1) / 2, dil);
   a.N = cout; a.bias = pc.bias; a.Y = y; a.ldy = ldy; a.act = act;
+  if (force_tile >= 100) {  // tests: the contraction reads 16-bit activation rows (rounded copy of x), tile = force_tile - 100
+    STTS_CHECK(precision != 0, "op_conv1d: 16-bit activation rows need a 16-bit operand mode");
+    unsigned short* x16 = nullptr;
+    STTS_HIP(hipMalloc(&x16, (size_t)s.rows() * ldx * sizeof(unsigned short)));
+    tmp.allocs.push_back(x16);
+    launch_cast_rows(st, precision, x, ldx, ldx, x16, ldx, s.rows());
+    a.seg[0].X = reinterpret_cast<const float*>(x16);
+    a.x16 = 1;
+    force_tile -= 100;
+  }
   STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, pc.npad, n_utt, s.max_len(), force_tile));
   STTS_HIP(hipStreamSynchronize(st));
   return 0;
@@ -625,6 +635,13 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, X, kc, 0, pc);
   a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy; a.tune = tune & 63;
+  unsigned short* X16 = nullptr;
+  if ((tune & 1024) && (tune & 384)) {  // bit 10: 16-bit activation rows (X rounded once, outside the timed launches)
+    STTS_HIP(hipMalloc(&X16, R * kc * sizeof(unsigned short)));
+    launch_cast_rows(st, pc.prec, X, kc, kc, X16, kc, R);
+    a.seg[0].X = reinterpret_cast<const float*>(X16);
+    a.x16 = 1;
+  }
   long long* dbg = nullptr;
   const size_t dbg_n = 8 * 16384;
   if (tune & 64) { STTS_HIP(hipMalloc(&dbg, dbg_n * 8)); STTS_HIP(hipMemset(dbg, 0, dbg_n * 8)); }
@@ -739,6 +756,7 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   }
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(B); (void)hipFree(so);
   if (W16) (void)hipFree(W16);
+  if (X16) (void)hipFree(X16);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;
   API_END

@@ -42,6 +42,31 @@ __global__ void __launch_bounds__(256) style_fc_kernel(const float* __restrict__
 // part layout: [(u * nchunk + chunk) * 2 + {0: mean, 1: M2}][ldp]
 // ---------------------------------------------------------------------------------------------
 constexpr int kStatChunk = 128;
+
+// Four consecutive outputs of a row, either fp32 or rounded (nearest even) to the operand type of the 16-bit modes: the
+// producers of contraction inputs write 16-bit rows directly (conv_gemm_f32<..., X16>); idx counts ELEMENTS of the row buffer.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4(float* Y, long idx, float a, float b, float c, float d, int prec16) {
+  if (prec16 == PREC_BF16) {
+    const bf16x4_t o = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(Y) + idx) = o;
+  } else if (prec16 == PREC_F16) {
+    const f16x4_t o = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    *reinterpret_cast<f16x4_t*>(reinterpret_cast<unsigned short*>(Y) + idx) = o;
+  } else {
+    *reinterpret_cast<float4*>(Y + idx) = make_float4(a, b, c, d);
+  }
+}
+// four consecutive 16-bit operands -> fp32
+__device__ __forceinline__ float4 load4_16(const unsigned short* X, long idx, int prec16) {
+  if (prec16 == PREC_BF16) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(X + idx);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  const f16x4_t v = *reinterpret_cast<const f16x4_t*>(X + idx);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
 __global__ void __launch_bounds__(256) adain_partial_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
                                                             float* __restrict__ part, int ldp, int nchunk) {
   __shared__ float red[8][33];
@@ -131,7 +156,8 @@ __global__ void __launch_bounds__(64) adain_affine_kernel(const float* __restric
 __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int C,
                                                           const int* __restrict__ seg_off, const float* __restrict__ part, int ldp, int nchunk,
                                                           const float* __restrict__ gb, int ld_gb, int gcol0, float eps, int act,
-                                                          const float* __restrict__ alpha) {
+                                                          const float* __restrict__ alpha, int out16) {
+  // out16: 0 = fp32 rows; PREC_BF16 / PREC_F16 = Y is a 16-bit row buffer (ldy in elements) read by the next contraction
   const int u = blockIdx.z;
   const int lo = seg_off[u], hi = seg_off[u + 1];
   const int r0 = lo + blockIdx.y * 64;
@@ -182,7 +208,7 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
       }
       o = make_float4(ov[0], ov[1], ov[2], ov[3]);
     }
-    *reinterpret_cast<float4*>(Y + (long)r * ldy + c4) = o;
+    store4(Y, (long)r * ldy + c4, o.x, o.y, o.z, o.w, out16);
   }
 }
 
@@ -198,6 +224,7 @@ struct LnOut {
   const float* g;  // adaptive: style table (row u), gamma at gcol0 + c, beta at gcol0 + C + c ; static: gamma[c]
   const float* b;  // static beta (ignored when adaptive)
   int ld_g, gcol0;
+  int prec16;      // 0: Y holds fp32 rows; PREC_BF16 / PREC_F16: Y is a 16-bit row buffer (ldy / ycol0 in elements)
 };
 // LnIn (optional): the row is not read from X but finished from the partial sums of a split-K contraction,
 //   x = (act(sum_k partial[k][row] + bias) [+ R[row]]) * alpha  in slice order (what splitk_reduce_kernel computes),
@@ -276,7 +303,7 @@ __global__ void __launch_bounds__(256) row_layernorm_kernel(const float* __restr
         y.y = act_apply((v[i].y - mean) * rstd * g.y + b.y, act);
         y.z = act_apply((v[i].z - mean) * rstd * g.z + b.z, act);
         y.w = act_apply((v[i].w - mean) * rstd * g.w + b.w, act);
-        *reinterpret_cast<float4*>(o.Y + (long)row * o.ldy + o.ycol0 + q * 4) = y;
+        store4(o.Y, (long)row * o.ldy + o.ycol0 + q * 4, y.x, y.y, y.z, y.w, o.prec16);
       }
     }
   }
@@ -518,7 +545,8 @@ __global__ void __launch_bounds__(256) to_channel_major_kernel(const float* __re
 // this kernel the last one (generator.py:344-358).  w is tap-major [ntaps][C].
 __global__ void __launch_bounds__(256) single_channel_conv_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
                                                                   const int* __restrict__ row_utt, const float* __restrict__ w, float bias,
-                                                                  int ntaps, float* __restrict__ Y, int ldy, int ycol, int n_rows) {
+                                                                  int ntaps, float* __restrict__ Y, int ldy, int ycol, int n_rows, int x16) {
+  // x16: 0 = X holds fp32 rows; PREC_BF16 / PREC_F16 = 16-bit rows (ldx in elements); the weights stay fp32 either way
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
@@ -532,7 +560,7 @@ __global__ void __launch_bounds__(256) single_channel_conv_kernel(const float* _
     const float* x = X + (long)g * ldx;
     const float* wt = w + (long)t * C;
     for (int q = lane; q < nv; q += 64) {
-      const float4 a = *reinterpret_cast<const float4*>(x + q * 4);
+      const float4 a = x16 ? load4_16(reinterpret_cast<const unsigned short*>(X), (long)g * ldx + q * 4, x16) : *reinterpret_cast<const float4*>(x + q * 4);
       const float4 b = *reinterpret_cast<const float4*>(wt + q * 4);
       acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
@@ -558,6 +586,36 @@ __global__ void __launch_bounds__(256) euler_step_kernel(float* __restrict__ x, 
 // out[i] = i * step, i < n  (segment offsets of equally sized planes)
 __global__ void seg_linear_kernel(int* __restrict__ out, int n, int step) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = i * step;
+}
+
+// fp32 rows -> 16-bit rows rounded to nearest even (the operand precision of the 16-bit modes): Y16[r][c] for c < ldy, zeros
+// for c >= cols.  For contraction inputs whose producer is not one of the kernels that write 16-bit rows themselves.
+template <int PREC>
+__global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict__ X, int ldx, int cols, unsigned short* __restrict__ Y, int ldy, long rows) {
+  const int q = ldy / 8;  // 16-byte groups of 8 output elements per row
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * q; i += (long)gridDim.x * 256) {
+    const long r = i / q;
+    const int c0 = (int)(i % q) * 8;
+    f32x4 out;
+    if constexpr (PREC == PREC_BF16) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)(c0 + e < cols ? X[r * ldx + c0 + e] : 0.0f);  // round to nearest even
+      out = __builtin_bit_cast(f32x4, o);
+    } else {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)(c0 + e < cols ? X[r * ldx + c0 + e] : 0.0f);
+      out = __builtin_bit_cast(f32x4, o);
+    }
+    *reinterpret_cast<f32x4*>(Y + r * ldy + c0) = out;
+  }
+}
+inline void launch_cast_rows(hipStream_t st, int prec, const float* X, int ldx, int cols, unsigned short* Y, int ldy, long rows) {
+  const dim3 grid((unsigned)std::min<long>(4096, std::max<long>(1, (rows * (ldy / 8) + 255) / 256)));
+  const size_t bytes = (size_t)rows * (cols * 4 + ldy * 2);
+  if (prec == PREC_BF16) STTS_LAUNCH_PROF("cast_rows_kernel", bytes, cast_rows_kernel<PREC_BF16>, grid, dim3(256), st, X, ldx, cols, Y, ldy, rows);
+  else STTS_LAUNCH_PROF("cast_rows_kernel", bytes, cast_rows_kernel<PREC_F16>, grid, dim3(256), st, X, ldx, cols, Y, ldy, rows);
 }
 
 inline void launch_scale_weight(hipStream_t st, dim3 grid, int prec, const float* W, const float* gx, int ld_gx, const float* gamma, void* Wu, int npad,

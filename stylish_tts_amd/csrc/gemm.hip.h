@@ -82,9 +82,14 @@ struct GemmArgs {
   SplitInfo* defer;       // host side: non-null = do not launch the reduce pass, report the partials instead (e.g. to a LayerNorm)
   int N;               // output channels actually stored (paired epilogues: channels of the result)
   const float* bias;   // [Npad] in packed row order, may be null
+  // 16-bit operand modes: every segment's X points to 16-bit rows already rounded to `prec` (ldx / xcol0 in elements);
+  // set by the callers whose producers write 16-bit activations (conv_gemm_f32<..., X16>)
+  int x16;
   // EPI_STORE
-  float* Y;
+  float* Y;            // may be null when only the 16-bit copy is wanted
   int ldy, ycol0;
+  unsigned short* Y16; // optional: the same values rounded to `prec` (operand of the next contraction), [rows, ldy16]
+  int ldy16, ycol16;
   const float* R;
   int ldr, rcol0;
   float alpha;
@@ -151,21 +156,24 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4 a, const f32x4 b, const f32
 // KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
 // partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
 // have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, bool XAFF = false, bool MSEG = true>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, bool XAFF = false, bool MSEG = true,
+          bool X16 = false>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
   static_assert(!(XAFF && GLDS), "the input affine lives on the register staging path");
+  static_assert(!X16 || (PREC != PREC_F32 && !XAFF && !GLDS && EPI == EPI_STORE), "16-bit activation rows: 16-bit operand modes, plain staging, store epilogue");
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
   constexpr bool B16 = PREC != PREC_F32;
   static_assert(!(B16 && GLDS), "16-bit operands use the register staging path");
   static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
   constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
   constexpr int TR = WR / 32, TC = WC / 32;
-  constexpr int XL = BN * 8 / NT;
+  constexpr int XL = X16 ? (BN * 4 + NT - 1) / NT : BN * 8 / NT;  // 16-byte X loads per thread per tile (16-bit rows: 4 per 32 channels)
   constexpr int WL = B16 ? (BM * 4 + NT - 1) / NT : BM * 8 / NT;  // 16-byte W loads per thread per tile
   static_assert(WR % 32 == 0 && WC % 32 == 0, "wave tile must be a multiple of 32x32");
-  static_assert((BN * 8) % NT == 0 && (B16 || (BM * 8) % NT == 0), "tile loads must divide over the block");
+  static_assert((X16 || (BN * 8) % NT == 0) && (B16 || (BM * 8) % NT == 0), "tile loads must divide over the block");
   static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
-  __shared__ f32x4 lds[2 * (BN + BM) * 8];
+  // two stages of [X rows | W rows] x 32 channels (16-bit operands: half of it; the K-group reduction of KSPLIT = 2 needs the full size)
+  __shared__ f32x4 lds[2 * (BN + BM) * ((B16 && KSPLIT == 1) ? 4 : 8)];
 
   // XCD-aware block -> tile map (guide T1; speed only, any placement is correct): workgroups are dealt round-robin
   // over the 8 XCDs, each with its own L2.  Re-number them so that one XCD works through a CONTIGUOUS range of
@@ -251,7 +259,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // scalar registers.  That lets the scheduler sink the address arithmetic, the global loads and the ds_writes into the
   // shadows of the MFMAs (one 32x32x2 MFMA occupies the matrix pipe for 64 cycles but issues in ~8).
   int s = 0, tap = 0, chunk = 0;
-  const float* gX = a.seg[0].X + a.seg[0].xcol0;
+  // (X16: X is a 16-bit buffer behind the float pointer type; xcol0 / ldx count its elements)
+  auto xbase = [&](const GemmSeg& g) {
+    return X16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.X) + g.xcol0) : g.X + g.xcol0;
+  };
+  const float* gX = xbase(a.seg[0]);
   const float* gW = a.seg[0].W + (long)utt * a.seg[0].w_utt_stride + (long)m0 * a.seg[0].ntaps * a.seg[0].kc;
   const unsigned short* gW16 = B16 ? a.seg[0].W16 + (long)utt * a.seg[0].w_utt_stride + (long)m0 * a.seg[0].ntaps * a.seg[0].kc : nullptr;
   int g_ldx = a.seg[0].ldx, g_kc = a.seg[0].kc, g_ntaps = a.seg[0].ntaps, g_dil = a.seg[0].dil, g_pad = a.seg[0].pad;
@@ -288,16 +300,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 #else
     constexpr bool hot = false;
 #endif
-    const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + (hot ? 0 : chunk * 32));
+    const char* xb = X16 ? reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(gX) + (long)lo * g_ldx + chunk * 32)
+                         : reinterpret_cast<const char*>(gX + (long)lo * g_ldx + (hot ? 0 : chunk * 32));
     const char* wb = B16 ? reinterpret_cast<const char*>(gW16 + tap * g_kc + chunk * 32)
                          : reinterpret_cast<const char*>((hot ? a.seg[0].W : gW) + (hot ? 0 : tap * g_kc + chunk * 32));
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
-      const int r = idx >> 3, sl = idx & 7;
+      const int r = X16 ? idx >> 2 : idx >> 3, sl = X16 ? idx & 3 : idx & 7;
       const int rel = (hot ? 0 : rel0) + r + shift;
       const int crel = min(max(rel, 0), len - 1);
-      const unsigned off = (unsigned)((crel * g_ldx + sl * 4) * 4);
+      const unsigned off = X16 ? (unsigned)((crel * g_ldx + sl * 8) * 2) : (unsigned)((crel * g_ldx + sl * 4) * 4);
       rs.x[i] = *reinterpret_cast<const f32x4*>(xb + off);
       rs.ok[i] = rel >= 0 && rel < len;
     }
@@ -322,7 +335,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       if (wrapt && !last) {  // uniform, taken at most twice per kernel
         ++s;
         const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
-        gX = n.X + n.xcol0;
+        gX = xbase(n);
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
@@ -353,9 +366,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
         const int idx = tid + i * NT;
-        const int r = idx >> 3, sl = idx & 7;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        Xh[(r * 4 + ((sl >> 1) ^ ((r >> 2) & 3))) * 2 + (sl & 1)] = pack4_16<PREC>(xin(rs, i));
+        if constexpr (X16) {  // rows arrive rounded: 16 bytes = 8 channels go straight into their slot
+          const int r = idx >> 2, sl = idx & 3;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if (BN * 4 % NT == 0 || idx < BN * 4) Xs[r * 4 + (sl ^ ((r >> 2) & 3))] = rs.ok[i] ? rs.x[i] : z;
+        } else {
+          const int r = idx >> 3, sl = idx & 7;
+          Xh[(r * 4 + ((sl >> 1) ^ ((r >> 2) & 3))) * 2 + (sl & 1)] = pack4_16<PREC>(xin(rs, i));
+        }
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
@@ -395,7 +413,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         it0 -= n_it;
         ++s;
         const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
-        gX = n.X + n.xcol0;
+        gX = xbase(n);
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
@@ -494,7 +512,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       if (wrapt && !last) {
         ++s;
         const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
-        gX = n.X + n.xcol0;
+        gX = xbase(n);
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
@@ -628,14 +646,21 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
             const long grow = row0 + rl;
             if (a.R) v += a.R[grow * a.ldr + a.rcol0 + n];
             v *= a.alpha;
-            a.Y[grow * a.ldy + a.ycol0 + n] = v;
+            if (a.Y) a.Y[grow * a.ldy + a.ycol0 + n] = v;
+            if constexpr (B16) {
+              if (a.Y16) {
+                if constexpr (PREC == PREC_BF16) reinterpret_cast<__bf16*>(a.Y16)[grow * a.ldy16 + a.ycol16 + n] = (__bf16)v;
+                else reinterpret_cast<_Float16*>(a.Y16)[grow * a.ldy16 + a.ycol16 + n] = (_Float16)v;
+              }
+            }
             ss += v * v;
           }
         }
         if (a.sumsq_part) {
           ss += __shfl_xor(ss, 32, 64);
-          if (lh == 0 && nok) {
-            const long t = (long)utt * a.ss_stride + by * (BN / 32) + (wn * TR + i);
+          const int sub = by * (BN / 32) + (wn * TR + i);  // 32-row sub-tile of the utterance; the consumer reads ceil(len / 32) of them
+          if (lh == 0 && nok && sub * 32 < hi - lo) {
+            const long t = (long)utt * a.ss_stride + sub;
             a.sumsq_part[t * a.ld_ss + n] = ss;
           }
         }
@@ -852,6 +877,13 @@ inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int
   if (a.compact) grid = dim3(npad / BM, a.tiles_y, a.ksplit > 1 ? a.ksplit : 1);
   switch (epi) {
     case EPI_STORE:
+      if constexpr (!GL && PR != PREC_F32 && KS == 1) {
+        if (a.x16) {  // 16-bit activation rows (written by the producing kernels): no conversion, half the staging bytes
+          if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, false, false, true>), grid, block, st, e0, e1, a);
+          else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, false, true, true>), grid, block, st, e0, e1, a);
+          break;
+        }
+      }
       if constexpr (!GL) {
         if (a.xaff) {
           if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true, false>), grid, block, st, e0, e1, a);
@@ -884,6 +916,9 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     STTS_CHECK(a.seg[i].kc % 32 == 0 && a.seg[i].ldx % 4 == 0 && a.seg[i].xcol0 % 4 == 0, "conv_gemm: segment %d misaligned (kc %d ldx %d xcol0 %d)", i,
                a.seg[i].kc, a.seg[i].ldx, a.seg[i].xcol0);
   }
+  if (a.x16)
+    for (int i = 0; i < a.nseg; ++i)
+      STTS_CHECK(a.prec != PREC_F32 && a.seg[i].ldx % 8 == 0 && a.seg[i].xcol0 % 8 == 0, "conv_gemm: 16-bit activation rows need ldx / xcol0 multiples of 8 (segment %d)", i);
   constexpr int kCUs = 256;
   const int mt = npad / 128;
   auto row_tiles = [&](int bn) -> long {  // exact when the host offsets are known (mixed lengths)
@@ -894,7 +929,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   };
   int iters = 0;
   for (int i = 0; i < a.nseg; ++i) iters += a.seg[i].ntaps * (a.seg[i].kc / 32);
-  const bool splittable = force_tile == 0 && epi == EPI_STORE && !a.sumsq_part;
+  // (the split-K reduce pass writes fp32 Y only: launches that want the 16-bit copy, or no fp32 output at all, stay whole)
+  const bool splittable = force_tile == 0 && epi == EPI_STORE && !a.sumsq_part && a.Y && !a.Y16;
   // A launch takes about ceil(blocks / 256 CUs) block-times however many blocks are co-resident: a CU's matrix pipes are
   // the shared resource (block-timeline trace, profiles/).  When the last round would be mostly empty (288 tiles = 1.125
   // rounds for a 3.5 s batch of 8), the whole rounds run as they are and the REMAINDER row tiles run as a second launch
@@ -947,7 +983,20 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       if (tile == 5 && blocks128 <= kCUs && a.prec == PREC_F32) tile = 8;
     }
   }
-  const int bn = (tile == 5 || tile == 8 || tile == 11) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
+  if (force_tile == 0 && a.prec != PREC_F32 && a.x16 && epi == EPI_STORE) {
+    // 16-bit activation rows: 256-row tiles once they fill the chip at least ~1.5 times.  128 x 256 (two blocks per CU, so
+    // one block's prologue / epilogue hides behind the other's K loop) unless K is deep (the k = 7 convs: >= 128 iterations),
+    // where the 256 x 256 tile's lower staging rate wins (B = 64: out conv 875 vs 896 us, prior conv 287 vs 302; but
+    // pwconv1 403 vs 213, decoder convs 200 vs 137: tools/gemm_bench.py TUNE=1152)
+    const long rt256 = row_tiles(256);
+    if (npad % 256 == 0 && iters >= 128 && rt256 * (npad / 256) >= 3 * kCUs / 2) tile = 14;
+    else if (rt256 * (npad / 128) >= 3 * kCUs / 2) tile = 15;
+    if (tile == 14 || tile == 15) plan = Plan();
+  }
+  STTS_CHECK(!(a.x16 && (tile == 8 || tile == 11 || tile == 13 || a.xaff)), "conv_gemm: 16-bit activation rows need a plain register-staged tile");
+  STTS_CHECK(!((tile == 14 || tile == 15) && (a.prec == PREC_F32 || epi != EPI_STORE)), "conv_gemm: tiles 14 / 15 are for 16-bit operand store launches");
+  STTS_CHECK(tile != 14 || npad % 256 == 0, "conv_gemm: tile 14 needs cout padded to 256");
+  const int bn = (tile == 14 || tile == 15) ? 256 : (tile == 5 || tile == 8 || tile == 11) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
   if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
   if (tile == 8) {
     plan.full_rt = row_tiles(bn);
@@ -1003,6 +1052,13 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
         case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
         case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
         case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
+        case 14:  // 256 cout x 256 rows, 8 waves of 64 x 128 (8 accumulator tiles): 16-bit operands at large batches, where the
+                  // 128x128 loop is bound by L2 -> LDS staging (47 B/clk/CU needed); this tile needs 31
+          if constexpr (PR != PREC_F32) launch_cfg<256, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+          break;
+        case 15:
+          if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+          break;
         case 11:
           if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves
           break;

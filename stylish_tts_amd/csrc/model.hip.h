@@ -770,15 +770,18 @@ inline dim3 rows_grid(const Seg& s, int per_row_work) {
   return dim3((unsigned)std::min<long>(std::max<long>(1, ceil_div((int)std::min<long>(total, 1 << 30), 256)), 512), s.n_utt);
 }
 
+constexpr long kRows16 = 12288;  // rows from which the 16-bit operand modes keep contraction inputs as 16-bit rows in HBM
+
 // AdaIN + activation: Y[:, :ldy] = act((1+gamma) * InstanceNorm(X[:, :C]) + beta), zeros in the pad columns.
 // part: scratch of adain_part_floats(s, C) floats.
 inline size_t adain_part_floats(const Seg& s, int C) { return (size_t)s.n_utt * ceil_div(s.max_len(), kStatChunk) * 2 * round_up(C, 32); }
+// out16: PREC_BF16 / PREC_F16 = Y is a 16-bit row buffer (ldy in elements), the input of a contraction in that operand mode
 inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int C, float* Y, int ldy, const float* style_out, int ld_style,
-                     int gcol0, int act, const float* alpha, float* part) {
+                     int gcol0, int act, const float* alpha, float* part, int out16 = 0) {
   const int nchunk = ceil_div(s.max_len(), kStatChunk), ldp = round_up(C, 32);
   STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk);
-  STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C + ldy) * 4, adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), 64), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
-                     part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha);
+  STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C * 4 + ldy * (out16 ? 2 : 4)), adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), 64), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
+                     part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha, out16);
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -787,7 +790,8 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
 // kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
 // scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [adain_part_floats(s, max(kcin, cout))]
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
-                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr) {
+                           float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr,
+                           unsigned short* xs16 = nullptr) {
   const int ml = s.max_len();
   // Small batches (launch-latency bound): AdaIN -> LeakyReLU is folded into the staging of the contraction that consumes
   // it (conv_gemm_f32<..., XAFF>): the statistics pass stays, a 64-thread kernel turns them into per-(utterance, channel)
@@ -812,9 +816,13 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   }
   const bool wino1 = !fold && wino && *wino && B.w1.ready && force_tile == 0;
   const bool wino2 = !fold && wino && *wino && B.w2.ready && !B.sc.W && force_tile == 0;
+  // 16-bit operand modes, large batches: the normalised activations are WRITTEN as 16-bit rows (act1 / act2 reinterpreted),
+  // so the contractions stage half the bytes and convert nothing; a learned shortcut reads a rounded copy of x (xs16)
+  const int h16 = (s.rows() >= kRows16 && B.conv1.prec != PREC_F32 && force_tile == 0 && (!B.sc.W || xs16) && ldx % 8 == 0) ? B.conv1.prec : 0;
   if (!fold && !wino1) {
-    STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ss));
+    STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ss, h16));
     set_seg(a, 0, act1, B.kcin, 0, B.conv1);
+    a.x16 = h16 != 0;
   }
   a.N = B.cout;
   a.bias = B.conv1.bias;
@@ -838,11 +846,17 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   } else if (wino2) {
     affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2);
   } else {
-    STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, ss));
+    STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, ss, h16));
     set_seg(b, 0, act2, B.cout, 0, B.conv2);
+    b.x16 = h16 != 0;
   }
   if (B.sc.W) {
-    set_seg(b, 1, x, ldx, 0, B.sc);
+    if (h16) {
+      launch_cast_rows(st, h16, x, ldx, B.cin, xs16, ldx, s.rows());
+      set_seg(b, 1, reinterpret_cast<const float*>(xs16), ldx, 0, B.sc);
+    } else {
+      set_seg(b, 1, x, ldx, 0, B.sc);
+    }
   } else {
     b.R = x;
     b.ldr = ldx;
@@ -881,6 +895,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
   if (R > 4096 && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
+  unsigned short* xs16 = (R >= kRows16 && c->prec != PREC_F32) ? ws.get<unsigned short>(R * ldcat) : nullptr;  // rounded copy of a block's input (shortcut conv)
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
   STTS_DRY_RETURN(ws);
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
@@ -899,13 +914,13 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->asr_res.npad, s.n_utt, s.max_len()));
   }
   const int lds = c->dec_style.ld();
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino));
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16));
   float* cur = xa;
   float* nxt = xb;
   for (int i = 1; i <= 4; ++i) {
     float* dst = i == 4 ? x_out : nxt;
     const int ldd = i == 4 ? ld_x : ldcat;
-    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino));
+    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, xs16));
     std::swap(cur, nxt);
   }
   return 0;
@@ -1173,14 +1188,28 @@ inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows
 
 // prior convs (generator.py:412-413) write straight into the concat slots [h, h+hp) of the two head inputs.  The two
 // convs are independent (and independent of decoder/flow), so the caller may put them on different streams.
-inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, WinoScratch* wino = nullptr) {
+inline bool vocoder_rows16(const stts_ctx* c, long rows) { return c->prec != PREC_F32 && rows >= kRows16; }
+
+// 16-bit operand modes, large batches: the head inputs are 16-bit row buffers (`head` reinterpreted, [rows, hc] elements) and
+// the conv reads a rounded copy of har (har16: scratch of rows * ld_har elements).
+inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, WinoScratch* wino = nullptr,
+                      unsigned short* har16 = nullptr) {
   const int h = c->d.gen_hidden, hp = h / 2, hc = h + hp;
   const PackedConv& w = which == 0 ? c->amp_prior : c->phase_prior;
   if (wino && *wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(6,7) form: 12 instead of 42 multiplies per 6 outputs
     return run_winograd(st, s, har, ld_har, c->wino_prior[which], head + h, hc, ACT_NONE, nullptr, 0, 1.0f, *wino);
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, har, ld_har, 0, w);
-  a.N = hp; a.bias = w.bias; a.Y = head; a.ldy = hc; a.ycol0 = h;
+  a.N = hp; a.bias = w.bias;
+  if (vocoder_rows16(c, s.rows())) {
+    STTS_CHECK(har16 && ld_har % 8 == 0, "prior_conv: 16-bit mode needs the rounded-copy scratch");
+    launch_cast_rows(st, c->prec, har, ld_har, kBins, har16, ld_har, s.rows());
+    a.seg[0].X = reinterpret_cast<const float*>(har16);
+    a.x16 = 1;
+    a.Y = nullptr; a.Y16 = reinterpret_cast<unsigned short*>(head); a.ldy16 = hc; a.ycol16 = h;
+  } else {
+    a.Y = head; a.ldy = hc; a.ycol0 = h;
+  }
   return launch_conv_gemm(st, a, EPI_STORE, w.npad, s.n_utt, s.max_len());
 }
 
@@ -1206,6 +1235,12 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   float* la = logamp_out ? logamp_out : ws.get<float>(R * ldlp);
   float* ph = phase_out ? phase_out : ws.get<float>(R * ldlp);
   const int ldl = logamp_out ? ld_lp : ldlp;
+  // 16-bit operand modes: every contraction input of the body is a 16-bit row buffer written by its producer (LayerNorm
+  // outputs, the SiLU output of pwconv1, the head inputs) - nrm / U / headA / headP are reinterpreted; mel gets a rounded copy
+  // (from kRows16 rows on: below that the contractions are latency-bound one-round launches and the extra copies cost more
+  //  than the staging they save - B = 8 x 3 s: 3 520 vs 3 360 utt/s)
+  const int p16 = (c->prec != PREC_F32 && vocoder_rows16(c, R)) ? c->prec : 0;
+  unsigned short* mel16 = p16 ? ws.get<unsigned short>(R * round_up(d.gen_input, 32)) : nullptr;
   float* yw = ws.get<float>((R + s.n_utt) * kWin);
   WinoScratch wino;
   if (c->wino_out[0].ready && c->wino_out[1].ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->wino_out[0]));
@@ -1218,7 +1253,14 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   // projector over cat[mel, logamp_prior, phase_prior] as three K segments (generator.py:414)
   {
     GemmArgs a = gemm_args(s);
-    set_seg(a, 0, mel, ld_mel, 0, c->proj_mel);
+    if (p16) {
+      const int ldm16 = round_up(d.gen_input, 32);
+      launch_cast_rows(st, p16, mel, ld_mel, d.gen_input, mel16, ldm16, R);
+      set_seg(a, 0, reinterpret_cast<const float*>(mel16), ldm16, 0, c->proj_mel);
+      a.x16 = 1;
+    } else {
+      set_seg(a, 0, mel, ld_mel, 0, c->proj_mel);
+    }
     set_seg(a, 1, headA, hc, h, c->proj_la);
     set_seg(a, 2, headP, hc, h, c->proj_ph);
     a.N = h; a.bias = c->proj_mel.bias; a.Y = xa; a.ldy = h;
@@ -1230,11 +1272,14 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     const ConvNextW& B = c->cnx[i];
     STTS_LAUNCH_PROF("dwconv_kernel", (size_t)R * h * 2 * 4, (dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), st, cur, h, dw, h, h, s.dev, B.dw_wt,
                        B.dw_b, B.K, (int)ACT_NONE);
-    LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0}, o1{};
+    LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0, p16}, o1{};
     STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE));
     GemmArgs a = gemm_args(s);
     set_seg(a, 0, nrm, h, 0, B.pw1);
-    a.N = inter; a.bias = B.pw1.bias; a.Y = U; a.ldy = inter; a.act = ACT_SILU;
+    a.N = inter; a.bias = B.pw1.bias; a.act = ACT_SILU;
+    a.x16 = p16 != 0;
+    if (p16) { a.Y = nullptr; a.Y16 = reinterpret_cast<unsigned short*>(U); a.ldy16 = inter; }  // GRN's sums of squares come from the fp32 values
+    else { a.Y = U; a.ldy = inter; }
     a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
     STTS_LAUNCH_PROF("grn_gx_kernel", (size_t)s.n_utt * ss_stride * inter * 4, grn_gx_kernel, dim3(ceil_div(inter, 256), s.n_utt), dim3(256), st, part, inter, ss_stride, s.dev, inter, gscale, inter);
@@ -1244,31 +1289,34 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     b.seg[0].W = w2u;
     b.seg[0].W16 = reinterpret_cast<const unsigned short*>(w2u);
     b.seg[0].w_utt_stride = (long)B.pw2.npad * B.pw2.kc;
+    b.x16 = p16 != 0;
     b.N = h; b.bias = B.pw2.bias; b.Y = nxt; b.ldy = h; b.R = cur; b.ldr = h;
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.pw2.npad, s.n_utt, ml));
     std::swap(cur, nxt);
   }
   // two AdaLN heads (eps 1e-5) into columns [0,512) of the head inputs (generator.py:417-423)
   {
-    LnOut o0{headA, hc, 0, sty, nullptr, lds, c->head_amp.col0}, o1{headP, hc, 0, sty, nullptr, lds, c->head_phase.col0};
+    LnOut o0{headA, hc, 0, sty, nullptr, lds, c->head_amp.col0, p16}, o1{headP, hc, 0, sty, nullptr, lds, c->head_phase.col0, p16};
     STTS_TRY(ln_launch(st, cur, h, h, R, row_utt, 1e-5f, 1, 2, o0, o1, ACT_NONE));
   }
   {
     GemmArgs a = gemm_args(s);
     set_seg(a, 0, headA, hc, 0, c->amp_out);
+    a.x16 = p16 != 0;
     a.N = kBins - 1; a.bias = c->amp_out.bias; a.Y = la; a.ldy = ldl;
     if (wino) STTS_TRY(run_winograd(st, s, headA, hc, c->wino_out[0], la, ldl, ACT_NONE, nullptr, 0, 1.0f, wino));
     else STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->amp_out.npad, s.n_utt, ml));
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, headP, hc, 0, c->phase_out);
+    b.x16 = p16 != 0;
     b.N = kBins - 1; b.bias = c->phase_out.bias; b.Y = ph; b.ldy = ldl;
     if (wino) STTS_TRY(run_winograd(st, s, headP, hc, c->wino_out[1], ph, ldl, ACT_NONE, nullptr, 0, 1.0f, wino));
     else STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
     const int kk = c->amp_out.ntaps;
     STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)R * (hc + 1) * 4, single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), st, headA, hc, hc, s.dev, row_utt, c->nyq_w[0],
-                       c->nyq_b[0], kk, la, ldl, kBins - 1, (int)R);
+                       c->nyq_b[0], kk, la, ldl, kBins - 1, (int)R, p16);
     STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)R * (hc + 1) * 4, single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), st, headP, hc, hc, s.dev, row_utt, c->nyq_w[1],
-                       c->nyq_b[1], kk, ph, ldl, kBins - 1, (int)R);
+                       c->nyq_b[1], kk, ph, ldl, kBins - 1, (int)R, p16);
   }
   STTS_LAUNCH_PROF("istft_frames_kernel", (size_t)R * 2 * kBins * 4, istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
   STTS_LAUNCH_PROF("istft_ola_kernel", (size_t)R * kHop * 4, istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), st, yw, s.dev, c->hann, audio);
@@ -1287,12 +1335,13 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     Arena tmp(ws.base + ws.used, ws.cap - ws.used, ws.offset0 + ws.used);  // released again before vocoder_body carves its own buffers
     WinoScratch wino;
     if (c->wino_prior[0].ready) wino.p = tmp.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
+    unsigned short* har16 = c->prec != PREC_F32 ? tmp.get<unsigned short>(R * ld_har) : nullptr;
     STTS_CHECK(tmp.ok, "vocoder_forward: workspace too small");
     if (dry_run().on) {
       dry_run().peak = std::max(dry_run().peak, tmp.offset0 + tmp.used);
     } else {
-      STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, &wino));
-      STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, &wino));
+      STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, &wino, har16));
+      STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, &wino, har16));
     }
   }
   return vocoder_body(c, st, s, mel, ld_mel, style, headA, headP, audio, logamp_out, phase_out, ld_lp, ws);
@@ -1326,12 +1375,13 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
     Arena a = stage();
     WinoScratch wino;
     if (c->wino_prior[0].ready) wino.p = a.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
+    unsigned short* har16 = c->prec != PREC_F32 ? a.get<unsigned short>(R * ldh) : nullptr;
     STTS_CHECK(a.ok, "frame_path: workspace too small");
     if (dry_run().on) {
       dry_run().peak = std::max(dry_run().peak, a.offset0 + a.used);
     } else {
-      STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino));
-      STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino));
+      STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino, har16));
+      STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino, har16));
     }
   }
   { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }

@@ -490,7 +490,7 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
       cur = bufs[i & 1];
     }
     hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)Rf, 4)), dim3(256), 0, st, cur, C, C, sf.dev, row_utt_f,
-                       br == 0 ? P.f0_w : P.n_w, br == 0 ? P.f0_b : P.n_b, 1, br == 0 ? f0 : nrg, 1, 0, (int)Rf);
+                       br == 0 ? P.f0_w : P.n_w, br == 0 ? P.f0_b : P.n_b, 1, br == 0 ? f0 : nrg, 1, 0, (int)Rf, 0);
   }
   STTS_HIP(hipGetLastError());
   return 0;

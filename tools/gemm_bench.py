@@ -14,7 +14,7 @@ shapes = [  # name, cin, cout, k
     ("square 4096 (1 utt)", 4096, 4096, 1),
     ("wino plane 768->1024 k1", 768, 1024, 1), ("wino plane 608->512 k1", 608, 512, 1),  # B=20 / B=12 x 960 rows = the component planes at B=8
 ]
-B, T4 = int(os.environ.get("B", 8)), 960
+B, T4 = int(os.environ.get("B", 8)), int(os.environ.get("T4", 960))
 flt = os.environ.get("SHAPES")
 tiles = [int(t) for t in os.environ.get("TILES", "2,5,6").split(",")]
 for name, cin, cout, k in shapes:
