@@ -33,6 +33,7 @@ int stts_ctx_create(const stts_model_dims* dims, int device, stts_ctx** out) {
   STTS_HIP(hipMemset(p, 0, 256));
   c->d_err = (int*)p;
   c->allocs.push_back(p);
+  c->alloc_tag.push_back(0);
   *out = c;
   return 0;
   API_END
@@ -73,12 +74,14 @@ int stts_finalize_weights(stts_ctx* c, int which) {
   API_BEGIN
   STTS_CHECK(c, "null ctx");
   STTS_HIP(hipSetDevice(c->device));
+  free_component_allocs(c, which);  // re-finalizing: the previous packing of these components goes away
   if (which & (STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR)) STTS_TRY(finalize_frame(c, which));
   const int ph = which & (STTS_W_SPEECH_TEXT | STTS_W_DURATION | STTS_W_PE_TEXT | STTS_W_PE_STYLE | STTS_W_PITCH_ENERGY);
   if (ph) {
     if (!c->phoneme) c->phoneme = std::make_shared<PhonemeModel>();
     STTS_TRY(finalize_phoneme(c, static_cast<PhonemeModel*>(c->phoneme.get()), ph));
     c->ready |= ph;
+    c->cur_tag = 0;
   }
   STTS_HIP(hipDeviceSynchronize());
   return 0;

@@ -121,6 +121,8 @@ struct stts_ctx {
   int device = 0;
   std::map<std::string, stts::HostTensor> host;
   std::vector<void*> allocs;
+  std::vector<int> alloc_tag;  // STTS_W_* component a device allocation belongs to (0: context lifetime); same length as allocs
+  int cur_tag = 0;             // tag of the allocations made right now (set by the finalize sections)
   int* d_err = nullptr;
   int ready = 0;  // STTS_W_* components finalized
   int prec = 0;   // contraction operand precision (stts::PREC_*), fixed before the first finalize
@@ -162,9 +164,29 @@ inline int dev_upload(stts_ctx* c, const std::vector<T>& h, T** out) {
   void* p = nullptr;
   STTS_HIP(hipMalloc(&p, std::max<size_t>(h.size(), 1) * sizeof(T)));
   c->allocs.push_back(p);
+  c->alloc_tag.push_back(c->cur_tag);
   if (!h.empty()) STTS_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   *out = (T*)p;
   return 0;
+}
+
+// Re-finalizing a component (a shim re-bound with other weights) releases the device buffers of its previous packing.
+inline void free_component_allocs(stts_ctx* c, int mask) {
+  bool any = false;
+  for (size_t i = 0; i < c->allocs.size(); ++i) any = any || (c->alloc_tag[i] & mask);
+  if (!any) return;
+  (void)hipDeviceSynchronize();  // kernels that read the old buffers may still be queued
+  size_t k = 0;
+  for (size_t i = 0; i < c->allocs.size(); ++i) {
+    if (c->alloc_tag[i] & mask) {
+      (void)hipFree(c->allocs[i]);
+    } else {
+      c->allocs[k] = c->allocs[i];
+      c->alloc_tag[k++] = c->alloc_tag[i];
+    }
+  }
+  c->allocs.resize(k);
+  c->alloc_tag.resize(k);
 }
 
 inline const HostTensor* find(stts_ctx* c, const std::string& name) {
@@ -245,6 +267,7 @@ inline int pack_rows(stts_ctx* c, const HostTensor& w, const HostTensor* bias, c
     void* d = nullptr;
     STTS_HIP(hipMalloc(&d, h.size() * sizeof(unsigned short)));
     c->allocs.push_back(d);
+    c->alloc_tag.push_back(c->cur_tag);
     STTS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     out->W16 = (unsigned short*)d;
   }
@@ -449,6 +472,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
              "generator.hidden_dim / conv_intermediate_dim must be multiples of 32");
   const std::string sp = "speech_predictor.";
   // tables
+  c->cur_tag = 0;
   if (!c->hann) {
     std::vector<float> h(kWin);
     for (int i = 0; i < kWin; ++i) h[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / kWin));
@@ -462,6 +486,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
   }
   // decoder (models/decoder.py:6-45)
   if (which & STTS_W_DECODER) {
+    c->cur_tag = STTS_W_DECODER;
     c->dec_style = StyleTable();
     c->dec_style.K = d.style_dim;
     HostTensor wf, wn;
@@ -484,6 +509,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
   }
   // prior + flow + post_flow (models/flow.py, models/speech_predictor.py:36-62)
   if (which & STTS_W_FLOW) {
+    c->cur_tag = STTS_W_FLOW;
     c->flow_style = StyleTable();
     c->flow_style.K = d.style_dim;
     const int fh = d.dec_hidden / 4, half = fh / 2;
@@ -530,6 +556,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
   }
   // generator (models/generator.py:340-438)
   if (which & STTS_W_GENERATOR) {
+    c->cur_tag = STTS_W_GENERATOR;
     c->gen_style = StyleTable();
     c->gen_style.K = d.style_dim;
     const std::string g = sp + "generator.";
@@ -599,6 +626,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
     STTS_TRY(add_style(c, &c->gen_style, g + "phase_final_layer_norm", h, &c->head_phase));
     STTS_TRY(upload_table(c, &c->gen_style));
   }
+  c->cur_tag = 0;
   c->ready |= which & (STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR);
   return 0;
 }

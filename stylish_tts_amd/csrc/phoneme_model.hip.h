@@ -187,10 +187,14 @@ inline int finalize_phoneme(stts_ctx* c, PhonemeModel* M, int which) {
   const int te_bit[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_TEXT};
   const int se_bit[3] = {STTS_W_DURATION, STTS_W_SPEECH_TEXT, STTS_W_PE_STYLE};
   for (int i = 0; i < 3; ++i) {
+    c->cur_tag = te_bit[i];
     if (which & te_bit[i]) STTS_TRY(pack_text_encoder(c, kTextEncPrefix[i], inter[i], &M->te[i]));
+    c->cur_tag = se_bit[i];
     if (which & se_bit[i]) STTS_TRY(pack_style_encoder(c, kStyleEncPrefix[i], inter[i], &M->se[i]));
   }
+  c->cur_tag = 0;
   if (which & STTS_W_DURATION) {
+    c->cur_tag = STTS_W_DURATION;
     DurationW& D = M->dur;
     D = DurationW();
     STTS_TRY(pack_prosody(c, "duration_predictor.prosody_encoder.", d.inter_dim, d.dur_layers, &D.table, &D.pros));
@@ -200,6 +204,7 @@ inline int finalize_phoneme(stts_ctx* c, PhonemeModel* M, int which) {
     D.ready = true;
   }
   if (which & STTS_W_PITCH_ENERGY) {
+    c->cur_tag = STTS_W_PITCH_ENERGY;
     PitchEnergyW& P = M->pe;
     P = PitchEnergyW();
     const std::string p = "pitch_energy_predictor.";

@@ -113,9 +113,17 @@ class HipModule(torch.nn.Module):
         return self._engine
 
     def _bind(self):
-        if self._dirty:
-            self._engine.load_state_dict(self.module_name, self._store, prefix=self.key_prefix)
-            self._engine.finalize(self.components)
+        """Shims share one engine per device and several may map to the same component (two Decoder instances, a Decoder
+        next to a SpeechPredictor, the reference's three TextEncoder instances): the engine remembers which shim packed
+        each component last, and a shim whose weights are not the packed ones re-binds before it runs."""
+        eng = self._engine
+        owners = eng.__dict__.setdefault("_owners", {})
+        bits = [1 << i for i in range(8) if self.components >> i & 1]
+        if self._dirty or any(owners.get(b) is not self for b in bits):
+            eng.load_state_dict(self.module_name, self._store, prefix=self.key_prefix)
+            eng.finalize(self.components)  # releases the previous packing of these components (stts_finalize_weights)
+            for b in bits:
+                owners[b] = self
             self._dirty = False
 
 

@@ -7,6 +7,7 @@ Tensors at this level are TIME-MAJOR packed rows (see include/stylish_hip.h); th
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, Mapping, Optional, Sequence
 
 import numpy as np
@@ -68,7 +69,10 @@ class HipModel:
         self.ctx = h
         self.precision = precision
         _lib.check(self.lib.stts_set_precision(self.ctx, self.PRECISIONS[precision]))
-        self._ws: Optional[torch.Tensor] = None
+        # grow-only workspaces, one per launch stream (stages issued on different streams may run concurrently)
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._pws: Dict[int, torch.Tensor] = {}
+        self._ws_lock = threading.Lock()
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -105,9 +109,12 @@ class HipModel:
     # ------------------------------------------------------------------ workspace
     def workspace(self, seg: Segments) -> torch.Tensor:
         need = int(self.lib.stts_frame_workspace_bytes(self.ctx, seg.rows, seg.n, seg.max_len))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        with self._ws_lock:
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _f32(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -216,12 +223,11 @@ class HipModel:
     def _ph_ws(self, n_tok: int, n_frames: int, n_utt: int) -> torch.Tensor:
         """Grow-only phoneme-stage workspace, one per launch stream (stages on different streams may run concurrently)."""
         need = int(self.lib.stts_phoneme_workspace_bytes(self.ctx, n_tok, n_frames, n_utt))
-        if not hasattr(self, "_pws"):
-            self._pws = {}
         key = torch.cuda.current_stream(self.device).cuda_stream
-        ws = self._pws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = self._pws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with self._ws_lock:
+            ws = self._pws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = self._pws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws
 
     def text_encoder(self, which: int, seg: Segments, tokens: torch.Tensor, return_hidden=False):

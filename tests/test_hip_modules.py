@@ -323,3 +323,25 @@ def test_synthesizer_vs_the_oracle_chain(mods, weights, cfg):
         ref, _, _ = O.speech_predictor_forward(tk[None], lengths, al, f0[fo : fo + Ti][None], en[fo : fo + Ti][None], nz, weights["speech_predictor"], cfg, hint)
         close(waves[i].cpu().numpy(), ref[0, 0], atol=1e-3, what=f"utt {i} waveform (teacher-forced pitch)")
         po, fo, f4 = po + P, fo + Ti, f4 + 4 * Ti
+
+
+def test_two_shims_of_one_component_do_not_run_each_others_weights(cfg):
+    """Two Decoder shims with different weights share the engine's decoder component: each call runs the
+    weights of the shim that is called (the engine tracks which shim packed a component last and re-binds), and re-binding
+    releases the previous packing instead of accumulating device buffers."""
+    from stylish_tts_amd import modules
+
+    g = load_golden("decoder")
+    a = modules.Decoder(dim_in=128, style_dim=64, dim_out=512, hidden_dim=512, residual_dim=64, cfg=cfg).load_synthetic(0)
+    b = modules.Decoder(dim_in=128, style_dim=64, dim_out=512, hidden_dim=512, residual_dim=64, cfg=cfg).load_synthetic(1)
+    args = (dev(g["asr"]), dev(g["pitch"]), dev(g["energy"]), dev(g["style"]))
+    xa, _ = a(*args)
+    xb, _ = b(*args)
+    close(xa, g["x"], what="shim A (golden weights)")
+    assert float((xa - xb).abs().max()) > 1e-2  # other weights, other result
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):  # alternate: every call re-binds
+        assert torch.equal(a(*args)[0], xa)
+        assert torch.equal(b(*args)[0], xb)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20  # 12 re-finalizations of ~40 MB each would show as ~0.5 GB
