@@ -11,7 +11,7 @@ g_ns = g_calls = 0
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
     n = r["Name"].replace("stts::", "").replace("void ", "").split("(")[0]
     t, c = float(r["TotalDurationNs"]), int(r["Calls"])
-    if "conv_gemm_f32" in n or "wn_layer" in n:
+    if "conv_gemm_f32" in n or "wn_layer" in n or "wn_fused" in n:
         g_ns += t
         g_calls += c
     elif "winograd_" in n:  # the transforms of a Winograd-form conv belong to its contraction launch
@@ -22,13 +22,20 @@ summary = {
     "source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (20 timed + 3 warm-up + 3 profiled steps)",
     "steps_in_trace": steps,
     "gpu_busy_ms_per_step": tot / 1e6 / steps,
-    "contraction_kernels": "conv_gemm_f32<*> + wn_layer_kernel (+ winograd_input/output_kernel of the Winograd-form convs)",
+    "contraction_kernels": "conv_gemm_f32<*> + wn_fused_kernel / wn_layer_kernel (+ winograd_input/output_kernel of the Winograd-form convs)",
     "contraction_launches_per_step": g_calls / steps,
     "contraction_avg_launch_us": g_ns / g_calls / 1e3,
     "contraction_ms_per_step": g_ns / 1e6 / steps,
-    "algorithmic_gflop_per_step": 568.36,
-    "contraction_tflops_from_rocprof": 568.36e9 / (g_ns / steps * 1e-9) / 1e12,
 }
+try:  # algorithmic and executed flops per step: bench.py's own accounting (stts_profile_report)
+    rl = json.load(open(out_prefix + "_bench.json"))["roofline"]
+    summary["algorithmic_gflop_per_step"] = rl["algorithmic_gflop_per_step"]
+    summary["executed_gflop_per_step"] = rl["executed_gflop_per_step"]
+    summary["contraction_tflops_from_rocprof"] = rl["algorithmic_gflop_per_step"] * 1e9 / (g_ns / steps * 1e-9) / 1e12
+    summary["contraction_executed_tflops_from_rocprof"] = rl["executed_gflop_per_step"] * 1e9 / (g_ns / steps * 1e-9) / 1e12
+    summary["bench_event_avg_launch_us"] = 1e3 * rl["avg_launch_ms"]
+except Exception:
+    pass
 # bench.py counts a Winograd-form conv (transforms + contraction) and a plain + remainder launch pair as ONE launch
 try:
     logical = json.load(open(out_prefix + "_bench.json"))["roofline"]["launches_per_step"]
