@@ -16,6 +16,7 @@
 #include "wn_layer.hip.h"
 #include "wn_layer_small.hip.h"
 #include "wn_fused.hip.h"
+#include "wn_fused16.hip.h"
 #include "winograd.hip.h"
 
 namespace stts {
@@ -86,7 +87,13 @@ struct WnFusedW {
   float* b3s = nullptr;
   float* W4 = nullptr;   // this layer's own `pre` (run by the tail of the layer before it in reverse order)
   float* b4 = nullptr;
-  bool ready = false;
+  // 16-bit operand modes (wn_fused16_kernel): the same matrices as 16-bit fragments, conv in direct (tap-major) form
+  unsigned short* H1[4] = {};
+  unsigned short* H2[4] = {};
+  unsigned short* H3 = nullptr;
+  unsigned short* H4 = nullptr;
+  bool ready = false;    // fp32 fragments packed
+  bool ready16 = false;  // 16-bit fragments packed
 };
 
 struct FlowLayerW {
@@ -408,7 +415,19 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
     STTS_TRY(get_weight(c, q + "enc.in_layers." + std::to_string(i), &w));
     STTS_GET(b, q + "enc.in_layers." + std::to_string(i) + ".bias");
     STTS_CHECK(w.shape[0] == 2 * C && w.shape[1] == C && w.shape[2] == 5 && (int)b->data.size() == 2 * C, "wn_fused: in_layers.%d has an unexpected shape", i);
-    for (int v = 0; v < 2; ++v) {
+    if (c->prec != PREC_F32) {
+      // direct form, K-major rows [tap][cin] so that k-step s = tap * 4 + (cin / 32) covers K offsets [32 s, 32 s + 32)
+      std::vector<std::vector<float>> kr((size_t)2 * C, std::vector<float>(5 * C));
+      for (int n = 0; n < 2 * C; ++n)
+        for (int ci = 0; ci < C; ++ci)
+          for (int k = 0; k < 5; ++k) kr[n][(size_t)k * C + ci] = w.data[((size_t)n * C + ci) * 5 + k];
+      // wave w, tile (half h, c): output rows h * 128 + 32 w + 16 c + col
+      const std::vector<unsigned short> f16v = pack_fragments16(c->prec, kWnWaves, 5 * C / 32, 4, [&](int wv, int t, int col) {
+        return kr[(size_t)(t >> 1) * C + 32 * wv + 16 * (t & 1) + col].data();
+      }, f32_to_bf16, f32_to_f16);
+      STTS_TRY(dev_upload(c, f16v, &o->H1[i]));
+    }
+    for (int v = 0; v < 2 && c->prec == PREC_F32; ++v) {
       WnFusedMats mt;
       STTS_CHECK(wn_fused_matrices(v == 0 ? 2 : 4, &mt), "wn_fused: F(%d,5) matrices failed their self-check", v == 0 ? 2 : 4);
       const int nc = mt.n;
@@ -433,14 +452,28 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
     STTS_CHECK((n_rs == 2 * C || n_rs == C) && wr.shape[1] == C && (n_rs == C) == (i == 3), "wn_fused: res_skip_layers.%d has an unexpected shape", i);
     const auto rr = rows_of(wr);
     const int nct = n_rs / 16 / kWnWaves;  // column tiles per wave
-    const std::vector<float> f2 = pack_fragments(kWnWaves, C / 16, nct, [&](int wv, int t, int col) { return rr[(size_t)16 * nct * wv + 16 * t + col].data(); });
-    STTS_TRY(dev_upload(c, f2, &o->W2[i]));
+    if (c->prec == PREC_F32) {
+      const std::vector<float> f2 = pack_fragments(kWnWaves, C / 16, nct, [&](int wv, int t, int col) { return rr[(size_t)16 * nct * wv + 16 * t + col].data(); });
+      STTS_TRY(dev_upload(c, f2, &o->W2[i]));
+    } else {
+      const std::vector<unsigned short> f2 = pack_fragments16(c->prec, kWnWaves, C / 32, nct, [&](int wv, int t, int col) {
+        return wr.data.data() + ((size_t)16 * nct * wv + 16 * t + col) * C;
+      }, f32_to_bf16, f32_to_f16);
+      STTS_TRY(dev_upload(c, f2, &o->H2[i]));
+    }
     STTS_TRY(dev_upload(c, br->data, &o->b2[i]));
   }
   STTS_CHECK(pm.shape[0] == C / 2 && pm.shape[1] == C && pl.shape[0] == C / 2, "wn_fused: proj has an unexpected shape");
   const auto rm = rows_of(pm), rl = rows_of(pl);
-  const std::vector<float> f3 = pack_fragments(kWnWaves, C / 16, 2, [&](int wv, int t, int col) { return (t == 0 ? rm : rl)[(size_t)16 * wv + col].data(); });
-  STTS_TRY(dev_upload(c, f3, &o->W3));
+  if (c->prec == PREC_F32) {
+    const std::vector<float> f3 = pack_fragments(kWnWaves, C / 16, 2, [&](int wv, int t, int col) { return (t == 0 ? rm : rl)[(size_t)16 * wv + col].data(); });
+    STTS_TRY(dev_upload(c, f3, &o->W3));
+  } else {
+    const std::vector<unsigned short> f3 = pack_fragments16(c->prec, kWnWaves, C / 32, 2, [&](int wv, int t, int col) {
+      return (t == 0 ? pm : pl).data.data() + ((size_t)16 * wv + col) * C;
+    }, f32_to_bf16, f32_to_f16);
+    STTS_TRY(dev_upload(c, f3, &o->H3));
+  }
   STTS_TRY(dev_upload(c, pmb.data, &o->b3m));
   STTS_TRY(dev_upload(c, plb.data, &o->b3s));
   HostTensor wp;
@@ -448,10 +481,18 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
   STTS_GET(bp, q + "pre.bias");
   STTS_CHECK(wp.shape[0] == C && wp.shape[1] == C / 2, "wn_fused: pre has an unexpected shape");
   const auto rp = rows_of(wp);
-  const std::vector<float> f4 = pack_fragments(kWnWaves, C / 32, 2, [&](int wv, int t, int col) { return rp[(size_t)32 * wv + 16 * t + col].data(); });
-  STTS_TRY(dev_upload(c, f4, &o->W4));
+  if (c->prec == PREC_F32) {
+    const std::vector<float> f4 = pack_fragments(kWnWaves, C / 32, 2, [&](int wv, int t, int col) { return rp[(size_t)32 * wv + 16 * t + col].data(); });
+    STTS_TRY(dev_upload(c, f4, &o->W4));
+  } else {
+    const std::vector<unsigned short> f4 = pack_fragments16(c->prec, kWnWaves, C / 64, 2, [&](int wv, int t, int col) {
+      return wp.data.data() + ((size_t)32 * wv + 16 * t + col) * (C / 2);
+    }, f32_to_bf16, f32_to_f16);
+    STTS_TRY(dev_upload(c, f4, &o->H4));
+  }
   STTS_TRY(dev_upload(c, bp->data, &o->b4));
-  o->ready = true;
+  o->ready = c->prec == PREC_F32;
+  o->ready16 = c->prec != PREC_F32;
   return 0;
 }
 
@@ -545,7 +586,7 @@ inline int finalize_frame(stts_ctx* c, int which) {
       pcb.data.insert(pcb.data.end(), plb->data.begin(), plb->data.end());
       STTS_TRY(pack_rows(c, pc, &pcb, paired_rows(half, 0, half), 0, fh, fh, half, &L.proj));
       L.fused = WnFusedW();
-      if (c->prec == PREC_F32 && fh == kWnC && !getenv("STTS_NO_WN_FUSED")) STTS_TRY(pack_wn_fused(c, q, pm, pl, *pmb, *plb, &L.fused));
+      if (fh == kWnC && !getenv("STTS_NO_WN_FUSED")) STTS_TRY(pack_wn_fused(c, q, pm, pl, *pmb, *plb, &L.fused));
       HostTensor cw;
       STTS_TRY(get_weight(c, q + "enc.cond_layer", &cw));
       STTS_GET(cb, q + "enc.cond_layer.bias");
@@ -1068,6 +1109,17 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       if (force == 2 || force == 4) fused_m = force;
     }
   }
+  // 16-bit operand modes: wn_fused16_kernel on 64- or 128-row blocks (the taller block halves the weight stream per row; it
+  // needs ~1.5 chip rounds of blocks to pay)
+  int fused16_rt = 0;
+  if (c->prec != PREC_F32 && !generic && c->flow[0].fused.ready16) {
+    long b128 = 0;
+    for (int u = 0; u < s.n_utt; ++u) b128 += ceil_div(s.host[u + 1] - s.host[u], 128);
+    fused16_rt = b128 >= 384 ? 8 : 4;
+    const int force = getenv("STTS_WN_RT") ? atoi(getenv("STTS_WN_RT")) : 0;  // tests / tools
+    if (force == 4 || force == 8) fused16_rt = force;
+    if (force == -1) fused16_rt = 0;  // the staged kernel
+  }
   auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
   for (int f = 7; f >= 0; --f) {
     const FlowLayerW& L = c->flow[f];
@@ -1134,7 +1186,8 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         e1 = prof.next();
         const double rest = 2.0 * (double)R * (double)L.rs[i].N * fh + extra, conv = 2.0 * (double)R * 2 * fh * 5 * fh;
         // the fused kernel executes F(M,5): M + 4 instead of 5 M products per channel and group of M rows
-        prof.add(fused_m ? "wn_fused_kernel" : "wn_layer_kernel", 0, conv + rest, (fused_m ? conv * (fused_m + 4) / (5.0 * fused_m) : conv) + rest, 0.0);
+        prof.add(fused_m ? "wn_fused_kernel" : (fused16_rt ? "wn_fused16_kernel" : "wn_layer_kernel"), 0, conv + rest,
+                 (fused_m ? conv * (fused_m + 4) / (5.0 * fused_m) : conv) + rest, 0.0);
       }
       const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
       if (fused_m) {
@@ -1161,11 +1214,43 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         if (fused_m == 4) launch(std::integral_constant<int, 4>{});
         else launch(std::integral_constant<int, 2>{});
       }
+      else if (fused16_rt) {
+        WnFused16Args fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.Hin = hcur; fa.Hout = w.Hout; fa.Out = outf; fa.seg_off = s.dev;
+        fa.W1 = L.fused.H1[i]; fa.b1 = L.fused.b1[i]; fa.W2 = L.fused.H2[i]; fa.b2 = L.fused.b2[i];
+        fa.gate = cond; fa.ld_gate = w.ld_gate; fa.gcol0 = w.gcol0; fa.out_acc = w.out_acc; fa.tail = w.tail;
+        fa.W3 = L.fused.H3; fa.b3m = L.fused.b3m; fa.b3s = L.fused.b3s; fa.Z = w.Z; fa.ldz = w.ldz; fa.zcol0 = w.zcol0;
+        if (w.tail > 1) { fa.W4 = c->flow[f - 1].fused.H4; fa.b4 = c->flow[f - 1].fused.b4; fa.Hpre = w.Hpre; }
+        if (s.n_utt <= kWnSegInline) {
+          fa.n_inline = s.n_utt;
+          memcpy(fa.seg_inline, s.host, (s.n_utt + 1) * sizeof(int));
+        }
+        auto launch16 = [&](auto ptag, auto rtag) {
+          constexpr int P = decltype(ptag)::value, RTv = decltype(rtag)::value;
+          const dim3 fgrid(ceil_div(ml, 16 * RTv), s.n_utt);
+          if (i == 3) STTS_LAUNCH_TIMED((wn_fused16_kernel<P, RTv, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, fa);
+          else STTS_LAUNCH_TIMED((wn_fused16_kernel<P, RTv, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, fa);
+        };
+        using I1 = std::integral_constant<int, PREC_BF16>;
+        using I2 = std::integral_constant<int, PREC_F16>;
+        using R4 = std::integral_constant<int, 4>;
+        using R8 = std::integral_constant<int, 8>;
+        if (c->prec == PREC_BF16) { if (fused16_rt == 8) launch16(I1{}, R8{}); else launch16(I1{}, R4{}); }
+        else { if (fused16_rt == 8) launch16(I2{}, R8{}); else launch16(I2{}, R4{}); }
+      }
       // small batches (fp32): 16-row blocks, twice the workgroups at half the chain length (wn_layer_small.hip.h)
       else if (rows16) STTS_LAUNCH_TIMED(wn_layer_rows16_kernel, dim3(ceil_div(ml, 16), s.n_utt), dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_BF16>, wgrid, dim3(1024), st, e0, e1, w);
       else if (c->prec == PREC_F16) STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F16>, wgrid, dim3(1024), st, e0, e1, w);
       else STTS_LAUNCH_TIMED(wn_layer_kernel<PREC_F32>, wgrid, dim3(1024), st, e0, e1, w);
+      if (const char* dbgs = getenv("STTS_WN_DEBUG")) {  // diagnostics: stop after launch #n and hand back h (n > 0) or out (n < 0)
+        const int n = atoi(dbgs), k = (7 - f) * 4 + i + 1;
+        if (z_flow_out && (n == k || n == -k)) {
+          STTS_HIP(hipMemcpyAsync(z_flow_out, n > 0 ? (i < 3 ? hnext : hf) : outf, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
+          return 0;
+        }
+      }
       std::swap(hcur, hnext);
     }
     STTS_HIP(hipGetLastError());

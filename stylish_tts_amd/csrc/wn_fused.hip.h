@@ -39,7 +39,7 @@
 namespace stts {
 
 constexpr int kWnC = 128;    // flow hidden channels (dec_hidden / 4)
-constexpr int kWnRowPad = 64;  // rows of slack the kernel may READ past the last utterance in Hin / Out / Z (a whole block)
+constexpr int kWnRowPad = 128;  // rows of slack the kernels may READ past the last utterance in Hin / Out / Z (a whole block)
 constexpr int kWnWaves = 4;  // waves per block: one per SIMD (two per SIMD ran phase 1 at 62 % of the MFMA rate, one at 90 %: tools/probes/p1_probe.hip)
 
 // F(M, 5) transform matrices for the points {0, 1, -1, 2, -1/2 (, -2, 1/2), inf}: exact rationals, compile-time constants so

@@ -202,3 +202,46 @@ def test_phoneme_stages_16bit_vs_fp32(cfg, weights, prec):
     e16.close()
     for k, v in got.items():
         assert v < STAGE_TOL[prec][k], (prec, k, v)
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 2e-2), ("f16", 3e-3)])
+def test_flow_16bit_fused_kernel_variants(cfg, weights, rounded_oracle, prec, tol, monkeypatch):
+    """The reverse flow in the 16-bit operand modes: wn_fused16_kernel on 64- and 128-row blocks (picked by batch size in
+    production, forced here) and the staged wn_layer_kernel share their rounding points (h entering LDS, gated activations,
+    `out` before post, the coupled half before pre), so all three must sit within the mode's noise of the oracle whose
+    contraction operands are rounded at those points, on lengths that leave partial blocks and one-row utterances.
+    Tolerance: relative to max |z|; 8 coupling layers x 4 WaveNet layers of operand roundings (2^-9 bf16, 2^-11 fp16)."""
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.runtime import HipModel
+
+    hip = HipModel(cfg, 0, precision=prec)
+    hip.load_weights({"speech_predictor": weights["speech_predictor"]}, which=7)
+    w = weights["speech_predictor"]
+    lens = [129, 1, 70, 260, 2, 63]
+    s = segs(lens)
+    xs = [synth.normal(f"wn16.x{i}", (1, 512, L)) for i, L in enumerate(lens)]
+    st = (synth.normal("wn16.s", (len(lens), 64)) * 0.7).astype(np.float32)
+    ns = [synth.normal(f"wn16.n{i}", (1, 128, L)) for i, L in enumerate(lens)]
+    cat = lambda parts: dev(np.concatenate([p[0].T for p in parts]))  # noqa: E731
+    O = rounded_oracle(prec)
+    refs = []
+    for i in range(len(lens)):
+        z, _, _ = O.prior_encoder(xs[i], ns[i], w)
+        refs.append(O.flow_reverse(z, st[i : i + 1, :, None], w))
+    got = {}
+    for rt in ("4", "8", "-1"):
+        monkeypatch.setenv("STTS_WN_RT", rt)
+        _, _, zf = hip.prior_flow(s, cat(xs), dev(st), cat(ns), return_z=True)
+        got[rt] = zf.cpu().numpy()
+    hip.close()
+    errs = {}
+    for rt, zf in got.items():
+        e = 0.0
+        for i, L in enumerate(lens):
+            ref = refs[i]
+            e = max(e, float(np.abs(zf[s.host[i] : s.host[i + 1], :128].T[None] - ref).max() / np.abs(ref).max()))
+        errs[rt] = e
+    print(f"\n[{prec} flow vs rounded oracle] 64-row blocks {errs['4']:.1e}, 128-row blocks {errs['8']:.1e}, staged kernel {errs['-1']:.1e}")
+    assert np.isfinite(got["4"]).all() and np.isfinite(got["8"]).all()
+    for rt, e in errs.items():
+        assert e < tol, (prec, rt, errs)
