@@ -31,6 +31,32 @@ __global__ void __launch_bounds__(256) style_fc_kernel(const float* __restrict__
   }
 }
 
+// The same projection for larger batches: lane = utterance (64 per pass), every lane runs the K-long dot product of its own
+// style row with the wave's weight row (broadcast from LDS) - no cross-lane reduction per utterance (the kernel above spends a
+// 6-step shuffle reduction per (row, utterance): 51 us at 64 utterances, this one ~10).
+__global__ void __launch_bounds__(256) style_fc_batch_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ s,
+                                                              float* __restrict__ out, int J, int K, int n_utt, int lds_s, int ld_out) {
+  __shared__ float wrow[4][128];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wv;
+  if (j < J)
+    for (int k = lane; k < K; k += 64) wrow[wv][k] = W[(long)j * K + k];
+  __syncthreads();
+  if (j >= J) return;
+  const float bj = b[j];
+  for (int u0 = 0; u0 < n_utt; u0 += 64) {
+    const int u = u0 + lane;
+    if (u >= n_utt) break;
+    const float* sp = s + (long)u * lds_s;
+    float acc = 0.f;
+    for (int k = 0; k < K; k += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(sp + k);
+      acc += x.x * wrow[wv][k] + x.y * wrow[wv][k + 1] + x.z * wrow[wv][k + 2] + x.w * wrow[wv][k + 3];
+    }
+    out[(long)u * ld_out + j] = acc + bj;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // AdaIN = (1+gamma) * InstanceNorm(x) + beta, per (utterance, channel) over time, eps 1e-5, biased variance
 // (models/ada_norm.py:129-139).  Two launches:
@@ -540,33 +566,53 @@ __global__ void __launch_bounds__(256) to_channel_major_kernel(const float* __re
   }
 }
 
-// One extra output channel of a Conv1d as a dot product per row (one wave per row).  Used for the Nyquist bin of the
-// vocoder's output convs: 1025 = 8 x 128 + 1 output channels, so the GEMM computes 1024 of them with full tiles and
-// this kernel the last one (generator.py:344-358).  w is tap-major [ntaps][C].
-__global__ void __launch_bounds__(256) single_channel_conv_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
-                                                                  const int* __restrict__ row_utt, const float* __restrict__ w, float bias,
-                                                                  int ntaps, float* __restrict__ Y, int ldy, int ycol, int n_rows, int x16) {
-  // x16: 0 = X holds fp32 rows; PREC_BF16 / PREC_F16 = 16-bit rows (ldx in elements); the weights stay fp32 either way
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= n_rows) return;
-  const int u = row_utt[row];
+// One extra output channel of a Conv1d as a dot product per row.  Used for the Nyquist bin of the vocoder's output convs:
+// 1025 = 8 x 128 + 1 output channels, so the GEMM computes 1024 of them with full tiles and this kernel the last one
+// (generator.py:344-358).  w is tap-major [ntaps][C].  A wave owns kRows consecutive rows and loads each of the kRows + ntaps - 1
+// input rows it needs ONCE (a row-per-wave form re-read every row ntaps times: 0.27 ms at 61 440 rows); grid.y selects one
+// of up to two (input, weights, output) sets so both heads go in one launch.
+// x16: 0 = X holds fp32 rows; PREC_BF16 / PREC_F16 = 16-bit rows (ldx in elements); the weights stay fp32 either way.
+struct ChanConvSet {
+  const float* X;
+  const float* w;
+  float bias;
+  float* Y;
+};
+constexpr int kChanRows = 8, kChanTaps = 7;
+__global__ void __launch_bounds__(256) single_channel_conv_kernel(ChanConvSet s0, ChanConvSet s1, int ldx, int C, const int* __restrict__ seg_off, int ntaps,
+                                                                  int ldy, int ycol, int x16) {
+  const ChanConvSet& S = blockIdx.y == 0 ? s0 : s1;
+  const int u = blockIdx.z;
   const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int lane = threadIdx.x & 63;
+  const int r0 = lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * kChanRows;
+  if (r0 >= hi) return;
   const int pad = (ntaps - 1) / 2, nv = C / 4;
-  float acc = 0.f;
-  for (int t = 0; t < ntaps; ++t) {
-    const int g = row + t - pad;
-    if (g < lo || g >= hi) continue;
-    const float* x = X + (long)g * ldx;
-    const float* wt = w + (long)t * C;
-    for (int q = lane; q < nv; q += 64) {
-      const float4 a = x16 ? load4_16(reinterpret_cast<const unsigned short*>(X), (long)g * ldx + q * 4, x16) : *reinterpret_cast<const float4*>(x + q * 4);
-      const float4 b = *reinterpret_cast<const float4*>(wt + q * 4);
-      acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  float acc[kChanRows];
+#pragma unroll
+  for (int i = 0; i < kChanRows; ++i) acc[i] = 0.f;
+  for (int q = lane; q < nv; q += 64) {  // this lane's 4 channels: taps in registers, rows streamed once
+    float4 wt[kChanTaps];
+#pragma unroll
+    for (int t = 0; t < kChanTaps; ++t) wt[t] = t < ntaps ? *reinterpret_cast<const float4*>(S.w + (long)t * C + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < kChanRows + kChanTaps - 1; ++j) {
+      const int g = r0 + j - pad;
+      if (j >= kChanRows + ntaps - 1 || g < lo || g >= hi) continue;
+      const float4 a = x16 ? load4_16(reinterpret_cast<const unsigned short*>(S.X), (long)g * ldx + q * 4, x16)
+                           : *reinterpret_cast<const float4*>(S.X + (long)g * ldx + q * 4);
+#pragma unroll
+      for (int t = 0; t < kChanTaps; ++t) {
+        const int i = j - t;  // output row r0 + i takes input row r0 + i + t - pad = g
+        if (i >= 0 && i < kChanRows) acc[i] += a.x * wt[t].x + a.y * wt[t].y + a.z * wt[t].z + a.w * wt[t].w;
+      }
     }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) Y[(long)row * ldy + ycol] = acc + bias;
+#pragma unroll
+  for (int i = 0; i < kChanRows; ++i) {
+    const float v = wave_sum(acc[i]);
+    if (lane == 0 && r0 + i < hi) S.Y[(long)(r0 + i) * ldy + ycol] = v + S.bias;
+  }
 }
 
 __global__ void fill_kernel(float* p, long n, float v) {

@@ -829,6 +829,12 @@ inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, c
 }
 
 inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
+  if (n_utt >= 16 && t.K % 4 == 0 && t.K <= 128) {  // lane = utterance: no per-utterance reduction (same sums, other order: ~1e-7)
+    STTS_LAUNCH_PROF("style_fc_batch_kernel", (size_t)t.J * (t.K + n_utt) * 4, style_fc_batch_kernel, dim3(ceil_div(t.J, 4)), dim3(256), st, t.W, t.b, style, out,
+                     t.J, t.K, n_utt, t.K, t.ld());
+    STTS_HIP(hipGetLastError());
+    return 0;
+  }
   STTS_LAUNCH_PROF("style_fc_kernel", (size_t)t.J * (t.K + n_utt) * 4, style_fc_kernel, dim3(ceil_div(t.J, 4)), dim3(256), st, t.W, t.b, style, out, t.J, t.K, n_utt, t.K, t.ld());
   STTS_HIP(hipGetLastError());
   return 0;
@@ -1270,7 +1276,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
 // stage: harmonic source + STFT (models/generator.py:247-315, :32-44, :406-410)
 // ------------------------------------------------------------------------------------------------
 inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float* pitch, const float* noise, const float* init_phase,
-                         int batch_scope, float* prior_out, float* har_spec, float* har_phase, int ld, Arena& ws) {
+                         int batch_scope, float* prior_out, float* har_spec, float* har_phase, int ld, Arena& ws, int out16 = 0) {
   const long R = s.rows();
   double* prefix = ws.get<double>(R);
   float* stats = ws.get<float>(2 * s.n_utt);
@@ -1283,7 +1289,7 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
   STTS_LAUNCH_PROF("pcph_prep_kernel", (size_t)R * 12, pcph_prep_kernel, dim3(s.n_utt), dim3(256), st, pitch, s.dev, prefix, stats);
   STTS_LAUNCH_PROF("pcph_kernel", (size_t)R * kHop * 8, pcph_kernel, dim3(std::min(1024, ceil_div(s.max_len() * kHop, 256)), s.n_utt), dim3(256), st, pitch, s.dev, s.n_utt,
                      prefix, stats, noise, init_phase, batch_scope, sig, c->d_err);
-  STTS_LAUNCH_PROF("stft_kernel", (size_t)R * (kHop + 2 * kBins) * 4, stft_kernel, dim3(s.max_len(), s.n_utt), dim3(256), st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld);
+  STTS_LAUNCH_PROF("stft_kernel", (size_t)R * (kHop + 2 * kBins) * 4, stft_kernel, dim3(s.max_len(), s.n_utt), dim3(256), st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld, out16);
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -1306,7 +1312,7 @@ inline bool vocoder_rows16(const stts_ctx* c, long rows) { return c->prec != PRE
 // 16-bit operand modes, large batches: the head inputs are 16-bit row buffers (`head` reinterpreted, [rows, hc] elements) and
 // the conv reads a rounded copy of har (har16: scratch of rows * ld_har elements).
 inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, const float* har, int ld_har, float* head, WinoScratch* wino = nullptr,
-                      unsigned short* har16 = nullptr) {
+                      unsigned short* har16 = nullptr, bool har_is16 = false) {
   const int h = c->d.gen_hidden, hp = h / 2, hc = h + hp;
   const PackedConv& w = which == 0 ? c->amp_prior : c->phase_prior;
   if (wino && *wino && c->wino_prior[which].ready)  // k = 7 in Winograd F(6,7) form: 12 instead of 42 multiplies per 6 outputs
@@ -1315,9 +1321,9 @@ inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, cons
   set_seg(a, 0, har, ld_har, 0, w);
   a.N = hp; a.bias = w.bias;
   if (vocoder_rows16(c, s.rows())) {
-    STTS_CHECK(har16 && ld_har % 8 == 0, "prior_conv: 16-bit mode needs the rounded-copy scratch");
-    launch_cast_rows(st, c->prec, har, ld_har, kBins, har16, ld_har, s.rows());
-    a.seg[0].X = reinterpret_cast<const float*>(har16);
+    STTS_CHECK((har16 || har_is16) && ld_har % 8 == 0, "prior_conv: 16-bit mode needs the rounded-copy scratch");
+    if (!har_is16) launch_cast_rows(st, c->prec, har, ld_har, kBins, har16, ld_har, s.rows());
+    a.seg[0].X = har_is16 ? har : reinterpret_cast<const float*>(har16);
     a.x16 = 1;
     a.Y = nullptr; a.Y16 = reinterpret_cast<unsigned short*>(head); a.ldy16 = hc; a.ycol16 = h;
   } else {
@@ -1426,10 +1432,10 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     if (wino) STTS_TRY(run_winograd(st, s, headP, hc, c->wino_out[1], ph, ldl, ACT_NONE, nullptr, 0, 1.0f, wino));
     else STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, c->phase_out.npad, s.n_utt, ml));
     const int kk = c->amp_out.ntaps;
-    STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)R * (hc + 1) * 4, single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), st, headA, hc, hc, s.dev, row_utt, c->nyq_w[0],
-                       c->nyq_b[0], kk, la, ldl, kBins - 1, (int)R, p16);
-    STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)R * (hc + 1) * 4, single_channel_conv_kernel, dim3((unsigned)ceil_div((int)R, 4)), dim3(256), st, headP, hc, hc, s.dev, row_utt, c->nyq_w[1],
-                       c->nyq_b[1], kk, ph, ldl, kBins - 1, (int)R, p16);
+    STTS_CHECK(kk <= kChanTaps, "output conv kernel size %d > %d", kk, kChanTaps);
+    const ChanConvSet sa{headA, c->nyq_w[0], c->nyq_b[0], la}, sp{headP, c->nyq_w[1], c->nyq_b[1], ph};
+    STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)2 * R * (hc * (p16 ? 2 : 4) + 4), single_channel_conv_kernel,
+                     dim3((unsigned)ceil_div(ml, 4 * kChanRows), 2, s.n_utt), dim3(256), st, sa, sp, hc, hc, s.dev, kk, ldl, kBins - 1, p16);
   }
   STTS_LAUNCH_PROF("istft_frames_kernel", (size_t)R * 2 * kBins * 4, istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
   STTS_LAUNCH_PROF("istft_ola_kernel", (size_t)R * kHop * 4, istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), st, yw, s.dev, c->hann, audio);
@@ -1483,18 +1489,19 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   };
   // Measured: running the (independent) source -> STFT -> prior-conv chain on side streams next to decoder/flow gains
   // < 1 % at B = 8 (7.51 vs 7.57 ms/step): the decoder GEMMs already fill the chip, so the stages stay on one stream.
-  { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a)); }
+  // 16-bit operand modes, large batches: the spectra are only read by the prior convs, so the STFT writes them as 16-bit rows
+  const int h16 = vocoder_rows16(c, R) ? c->prec : 0;
+  { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a, h16)); }
   {
     Arena a = stage();
     WinoScratch wino;
     if (c->wino_prior[0].ready) wino.p = a.get<float>(wino_scratch_floats(s, c->wino_prior[0]));
-    unsigned short* har16 = c->prec != PREC_F32 ? a.get<unsigned short>(R * ldh) : nullptr;
     STTS_CHECK(a.ok, "frame_path: workspace too small");
     if (dry_run().on) {
       dry_run().peak = std::max(dry_run().peak, a.offset0 + a.used);
     } else {
-      STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino, har16));
-      STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino, har16));
+      STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino, nullptr, h16 != 0));
+      STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino, nullptr, h16 != 0));
     }
   }
   { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }

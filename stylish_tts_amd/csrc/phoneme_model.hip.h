@@ -494,8 +494,9 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
       STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss, 0, &wino));
       cur = bufs[i & 1];
     }
-    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div((int)Rf, 4)), dim3(256), 0, st, cur, C, C, sf.dev, row_utt_f,
-                       br == 0 ? P.f0_w : P.n_w, br == 0 ? P.f0_b : P.n_b, 1, br == 0 ? f0 : nrg, 1, 0, (int)Rf, 0);
+    const ChanConvSet cs{cur, br == 0 ? P.f0_w : P.n_w, br == 0 ? P.f0_b : P.n_b, br == 0 ? f0 : nrg};
+    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div(sf.max_len(), 4 * kChanRows), 1, sf.n_utt), dim3(256), 0, st, cs, cs, C, C, sf.dev, 1,
+                       1, 0, 0);
   }
   STTS_HIP(hipGetLastError());
   return 0;

@@ -184,8 +184,11 @@ __device__ __forceinline__ T2* fft_lds(T2* a, T2* b, const T2* tw, int tw_scale)
 // at the +-pi cut and meaningless at ~0 magnitude, so the SIGN of a rounding-level real/imaginary part decides a
 // 2*pi jump that the next conv sees linearly.  FP64 makes those signs those of the exact transform of the fp32
 // windowed samples; the work is negligible next to the contractions.
+// out16: 0 = fp32 rows; 1 (bf16) / 2 (fp16) = spec / phase are 16-bit row buffers (ld in elements): the operands of the prior convs
+// in the 16-bit modes, written here instead of being rounded in a separate pass.
 __global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ sig, const int* __restrict__ seg_off, const float* __restrict__ hann,
-                                                   const double2* __restrict__ twiddle, float* __restrict__ spec, float* __restrict__ phase, int ld) {
+                                                   const double2* __restrict__ twiddle, float* __restrict__ spec, float* __restrict__ phase, int ld,
+                                                   int out16) {
   constexpr int H = kNfft / 2;  // 1024
   __shared__ double2 A[H], Bf[H];
   const int u = blockIdx.y, f = blockIdx.x;
@@ -233,8 +236,20 @@ __global__ void __launch_bounds__(256) stft_kernel(const float* __restrict__ sig
       const float d = m + 1e-9f;
       p = atan2f(fi / d, fr / d);
     }
-    so[k] = m;
-    po[k] = p;
+    if (out16 == 0) {
+      so[k] = m;
+      po[k] = p;
+    } else {
+      unsigned short* s16 = reinterpret_cast<unsigned short*>(spec) + (long)(lo + f) * ld;
+      unsigned short* p16 = reinterpret_cast<unsigned short*>(phase) + (long)(lo + f) * ld;
+      if (out16 == 1) {
+        reinterpret_cast<__bf16*>(s16)[k] = (__bf16)m;
+        reinterpret_cast<__bf16*>(p16)[k] = (__bf16)p;
+      } else {
+        reinterpret_cast<_Float16*>(s16)[k] = (_Float16)m;
+        reinterpret_cast<_Float16*>(p16)[k] = (_Float16)p;
+      }
+    }
   }
 }
 
