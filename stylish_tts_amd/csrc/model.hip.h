@@ -1282,6 +1282,7 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
   float* stats = ws.get<float>(2 * s.n_utt);
   float* sig = prior_out ? prior_out : ws.get<float>(R * kHop);
   STTS_CHECK(ws.ok, "harmonic_stft: workspace too small");
+  STTS_CHECK(ld >= kBins && ld <= 64 * ((kBins + 63) / 64), "harmonic_stft: row stride %d outside [%d, %d]", ld, kBins, 64 * ((kBins + 63) / 64));
   STTS_DRY_RETURN(ws);
   for (int u = 0; u < s.n_utt; ++u)
     STTS_CHECK((long)(s.host[u + 1] - s.host[u]) * kHop > kNfft / 2, "utterance %d too short for reflect padding (%d frames; need > %d samples)", u,
@@ -1289,7 +1290,7 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
   STTS_LAUNCH_PROF("pcph_prep_kernel", (size_t)R * 12, pcph_prep_kernel, dim3(s.n_utt), dim3(256), st, pitch, s.dev, prefix, stats);
   STTS_LAUNCH_PROF("pcph_kernel", (size_t)R * kHop * 8, pcph_kernel, dim3(std::min(1024, ceil_div(s.max_len() * kHop, 256)), s.n_utt), dim3(256), st, pitch, s.dev, s.n_utt,
                      prefix, stats, noise, init_phase, batch_scope, sig, c->d_err);
-  STTS_LAUNCH_PROF("stft_kernel", (size_t)R * (kHop + 2 * kBins) * 4, stft_kernel, dim3(s.max_len(), s.n_utt), dim3(256), st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld, out16);
+  STTS_LAUNCH_PROF("stft_kernel", (size_t)R * (kHop + 2 * kBins) * 4, stft_kernel, dim3((s.max_len() + kFftWaves - 1) / kFftWaves, s.n_utt), dim3(64 * kFftWaves), st, sig, s.dev, c->hann, c->twiddle64, har_spec, har_phase, ld, out16);
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -1437,7 +1438,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)2 * R * (hc * (p16 ? 2 : 4) + 4), single_channel_conv_kernel,
                      dim3((unsigned)ceil_div(ml, 4 * kChanRows), 2, s.n_utt), dim3(256), st, sa, sp, hc, hc, s.dev, kk, ldl, kBins - 1, p16);
   }
-  STTS_LAUNCH_PROF("istft_frames_kernel", (size_t)R * 2 * kBins * 4, istft_frames_kernel, dim3(ml + 1, s.n_utt), dim3(256), st, la, ph, ldl, s.dev, c->hann, c->twiddle, yw);
+  STTS_LAUNCH_PROF("istft_frames_kernel", (size_t)R * 2 * kBins * 4, istft_frames_kernel, dim3((ml + 1 + kFftWaves - 1) / kFftWaves, s.n_utt), dim3(64 * kFftWaves), st, la, ph, ldl, s.dev, c->hann, c->twiddle64, yw);
   STTS_LAUNCH_PROF("istft_ola_kernel", (size_t)R * kHop * 4, istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), st, yw, s.dev, c->hann, audio);
   STTS_HIP(hipGetLastError());
   return 0;
