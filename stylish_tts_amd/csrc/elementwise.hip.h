@@ -634,11 +634,12 @@ __global__ void seg_linear_kernel(int* __restrict__ out, int n, int step) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = i * step;
 }
 
-// fp32 rows -> 16-bit rows rounded to nearest even (the operand precision of the 16-bit modes): Y16[r][c] for c < ldy, zeros
+// fp32 rows -> 16-bit rows rounded to nearest even (the operand precision of the 16-bit modes): Y16[r][c] for c < width, zeros
 // for c >= cols.  For contraction inputs whose producer is not one of the kernels that write 16-bit rows themselves.
 template <int PREC>
-__global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict__ X, int ldx, int cols, unsigned short* __restrict__ Y, int ldy, long rows) {
-  const int q = ldy / 8;  // 16-byte groups of 8 output elements per row
+__global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict__ X, int ldx, int cols, unsigned short* __restrict__ Y, int ldy, int width,
+                                                        long rows) {
+  const int q = width / 8;  // 16-byte groups of 8 output elements per row
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * q; i += (long)gridDim.x * 256) {
     const long r = i / q;
     const int c0 = (int)(i % q) * 8;
@@ -657,11 +658,13 @@ __global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(Y + r * ldy + c0) = out;
   }
 }
-inline void launch_cast_rows(hipStream_t st, int prec, const float* X, int ldx, int cols, unsigned short* Y, int ldy, long rows) {
-  const dim3 grid((unsigned)std::min<long>(4096, std::max<long>(1, (rows * (ldy / 8) + 255) / 256)));
-  const size_t bytes = (size_t)rows * (cols * 4 + ldy * 2);
-  if (prec == PREC_BF16) STTS_LAUNCH_PROF("cast_rows_kernel", bytes, cast_rows_kernel<PREC_BF16>, grid, dim3(256), st, X, ldx, cols, Y, ldy, rows);
-  else STTS_LAUNCH_PROF("cast_rows_kernel", bytes, cast_rows_kernel<PREC_F16>, grid, dim3(256), st, X, ldx, cols, Y, ldy, rows);
+// width: columns written per row (a multiple of 8; 0 = the whole row stride ldy)
+inline void launch_cast_rows(hipStream_t st, int prec, const float* X, int ldx, int cols, unsigned short* Y, int ldy, long rows, int width = 0) {
+  if (width == 0) width = ldy;
+  const dim3 grid((unsigned)std::min<long>(4096, std::max<long>(1, (rows * (width / 8) + 255) / 256)));
+  const size_t bytes = (size_t)rows * (cols * 4 + width * 2);
+  if (prec == PREC_BF16) STTS_LAUNCH_PROF("cast_rows_kernel", bytes, cast_rows_kernel<PREC_BF16>, grid, dim3(256), st, X, ldx, cols, Y, ldy, width, rows);
+  else STTS_LAUNCH_PROF("cast_rows_kernel", bytes, cast_rows_kernel<PREC_F16>, grid, dim3(256), st, X, ldx, cols, Y, ldy, width, rows);
 }
 
 inline void launch_scale_weight(hipStream_t st, dim3 grid, int prec, const float* W, const float* gx, int ld_gx, const float* gamma, void* Wu, int npad,

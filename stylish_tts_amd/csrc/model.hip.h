@@ -866,7 +866,9 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
 // scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [adain_part_floats(s, max(kcin, cout))]
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
                            float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr,
-                           unsigned short* xs16 = nullptr) {
+                           unsigned short* xs16 = nullptr, bool xs16_ready = false, unsigned short* y16 = nullptr, int ldy16 = 0) {
+  // xs16: [rows, ldx] 16-bit scratch for the rounded copy of x a learned shortcut reads (16-bit modes, large batches);
+  // xs16_ready: it already holds that copy (the previous block's conv2 wrote it).  y16: also write y rounded, as [rows, ldy16].
   const int ml = s.max_len();
   // Small batches (launch-latency bound): AdaIN -> LeakyReLU is folded into the staging of the contraction that consumes
   // it (conv_gemm_f32<..., XAFF>): the statistics pass stays, a 64-thread kernel turns them into per-(utterance, channel)
@@ -927,7 +929,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   }
   if (B.sc.W) {
     if (h16) {
-      launch_cast_rows(st, h16, x, ldx, B.cin, xs16, ldx, s.rows());
+      if (!xs16_ready) launch_cast_rows(st, h16, x, ldx, B.cin, xs16, ldx, s.rows());
       set_seg(b, 1, reinterpret_cast<const float*>(xs16), ldx, 0, B.sc);
     } else {
       set_seg(b, 1, x, ldx, 0, B.sc);
@@ -941,11 +943,17 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   b.Y = y;
   b.ldy = ldy;
   b.alpha = 0.70710678118654752440f;
+  const bool y16_epi = y16 && h16 && !wino2;  // the 16-bit contraction's epilogue rounds y for the next block's shortcut
+  if (y16_epi) {
+    b.Y16 = y16;
+    b.ldy16 = ldy16;
+  }
   if (wino2) {
     STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, *wino, act2, B.cout));
   } else {
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
   }
+  if (y16 && !y16_epi) launch_cast_rows(st, B.conv1.prec, y, ldy, B.cout, y16, ldy16, s.rows(), B.cout);  // (cout % 8 == 0: caller)
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -970,7 +978,11 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
   if (R > 4096 && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
-  unsigned short* xs16 = (R >= kRows16 && c->prec != PREC_F32) ? ws.get<unsigned short>(R * ldcat) : nullptr;  // rounded copy of a block's input (shortcut conv)
+  // 16-bit modes, large batches: rounded copies of the blocks' inputs for the learned shortcuts, ping-pong like xa / xb: a block's
+  // conv2 epilogue writes the hidden columns of the next block's copy, the constant columns (asr_res, F0, N) are rounded once
+  const bool x16 = R >= kRows16 && c->prec != PREC_F32 && d.dec_hidden % 8 == 0;
+  unsigned short* xs16a = x16 ? ws.get<unsigned short>(R * ldcat) : nullptr;
+  unsigned short* xs16b = x16 ? ws.get<unsigned short>(R * ldcat) : nullptr;
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
   STTS_DRY_RETURN(ws);
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));
@@ -989,14 +1001,26 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->asr_res.npad, s.n_utt, s.max_len()));
   }
   const int lds = c->dec_style.ld();
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16));
+  const int ctail = d.dec_hidden & ~7, ntail = ldcat - ctail;  // constant columns (from the 8-aligned column at or below dec_hidden)
+  auto cast_tail = [&](const float* src, unsigned short* dst) {
+    launch_cast_rows(st, c->prec, src + ctail, ldcat, ccat - ctail, dst + ctail, ldcat, R, ntail);
+  };
+  // dec[0] rounds its own (narrow) input into xs16b as scratch, so xs16b's constant columns are filled after it
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat));
+  if (x16) {
+    cast_tail(xa, xs16a);
+    cast_tail(xb, xs16b);
+  }
   float* cur = xa;
   float* nxt = xb;
+  unsigned short* cur16 = xs16a;
+  unsigned short* nxt16 = xs16b;
   for (int i = 1; i <= 4; ++i) {
     float* dst = i == 4 ? x_out : nxt;
     const int ldd = i == 4 ? ld_x : ldcat;
-    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, xs16));
+    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat));
     std::swap(cur, nxt);
+    std::swap(cur16, nxt16);
   }
   return 0;
 }
@@ -1061,7 +1085,9 @@ inline void wn_trace_report(hipStream_t st) {
 // stage: PriorEncoder + reverse flow + post_flow (models/flow.py:311-315, :132-151, :196-218, :63-88)
 // ------------------------------------------------------------------------------------------------
 inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const float* x, int ld_x, const float* style, const float* noise,
-                              float* mel, int ld_mel, float* z_prior_out, float* z_flow_out, Arena& ws) {
+                              float* mel, int ld_mel, float* z_prior_out, float* z_flow_out, Arena& ws, unsigned short* mel16 = nullptr,
+                              int ld_mel16 = 0) {
+  // mel16: also write mel rounded to the operand precision (the vocoder's projector reads it; 16-bit modes, large batches)
   const stts_model_dims& d = c->d;
   const long R = s.rows();
   const int fh = d.dec_hidden / 4, half = fh / 2, ml = s.max_len();
@@ -1268,7 +1294,12 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, z, fh, 0, c->post_flow);
   a.N = d.dec_hidden; a.bias = c->post_flow.bias; a.Y = mel; a.ldy = ld_mel;
+  if (mel16 && c->post_flow.prec != PREC_F32) {
+    a.Y16 = mel16;
+    a.ldy16 = ld_mel16;
+  }
   STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, c->post_flow.npad, s.n_utt, ml));
+  if (mel16 && c->post_flow.prec == PREC_F32) launch_cast_rows(st, c->prec, mel, ld_mel, d.dec_hidden, mel16, ld_mel16, R);
   return 0;
 }
 
@@ -1336,7 +1367,8 @@ inline int prior_conv(stts_ctx* c, hipStream_t st, const Seg& s, int which, cons
 // everything after the prior convs: projector, ConvNeXt blocks, heads, output convs, iSTFT (generator.py:414-433).
 // headA / headP [rows, 768]: columns [512, 768) already hold logamp_prior / phase_prior.
 inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* mel, int ld_mel, const float* style, float* headA, float* headP,
-                        float* audio, float* logamp_out, float* phase_out, int ld_lp, Arena& ws) {
+                        float* audio, float* logamp_out, float* phase_out, int ld_lp, Arena& ws, const unsigned short* mel16_in = nullptr) {
+  // mel16_in: [rows, round_up(gen_input, 32)] mel already rounded to the operand precision by its producer (frame_path)
   const stts_model_dims& d = c->d;
   const long R = s.rows();
   const int h = d.gen_hidden, hp = h / 2, hc = h + hp, inter = d.gen_inter, ml = s.max_len();
@@ -1360,7 +1392,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   // (from kRows16 rows on: below that the contractions are latency-bound one-round launches and the extra copies cost more
   //  than the staging they save - B = 8 x 3 s: 3 520 vs 3 360 utt/s)
   const int p16 = (c->prec != PREC_F32 && vocoder_rows16(c, R)) ? c->prec : 0;
-  unsigned short* mel16 = p16 ? ws.get<unsigned short>(R * round_up(d.gen_input, 32)) : nullptr;
+  unsigned short* mel16 = (p16 && !mel16_in) ? ws.get<unsigned short>(R * round_up(d.gen_input, 32)) : nullptr;
   float* yw = ws.get<float>((R + s.n_utt) * kWin);
   WinoScratch wino;
   if (c->wino_out[0].ready && c->wino_out[1].ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->wino_out[0]));
@@ -1375,8 +1407,8 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     GemmArgs a = gemm_args(s);
     if (p16) {
       const int ldm16 = round_up(d.gen_input, 32);
-      launch_cast_rows(st, p16, mel, ld_mel, d.gen_input, mel16, ldm16, R);
-      set_seg(a, 0, reinterpret_cast<const float*>(mel16), ldm16, 0, c->proj_mel);
+      if (!mel16_in) launch_cast_rows(st, p16, mel, ld_mel, d.gen_input, mel16, ldm16, R);
+      set_seg(a, 0, reinterpret_cast<const float*>(mel16_in ? mel16_in : mel16), ldm16, 0, c->proj_mel);
       a.x16 = 1;
     } else {
       set_seg(a, 0, mel, ld_mel, 0, c->proj_mel);
@@ -1479,6 +1511,8 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   float* hp = top.get<float>(R * ldh);
   float* headA = top.get<float>(R * hc);
   float* headP = top.get<float>(R * hc);
+  const int ldm16 = round_up(c->d.gen_input, 32);
+  unsigned short* mel16 = (c->prec != PREC_F32 && vocoder_rows16(c, R) && c->d.gen_input == dh) ? top.get<unsigned short>(R * ldm16) : nullptr;
   const size_t side_bytes = (size_t)R * (sizeof(double) + kHop * sizeof(float)) + 4096 + 8 * s.n_utt;
   const size_t side_off = top.used;
   char* side_ws = top.get<char>(side_bytes);
@@ -1506,8 +1540,8 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
     }
   }
   { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
-  { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a)); }
-  { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, dh, style, headA, headP, audio, nullptr, nullptr, 0, a)); }
+  { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a, mel16, ldm16)); }
+  { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, dh, style, headA, headP, audio, nullptr, nullptr, 0, a, mel16)); }
   return 0;
 }
 
