@@ -177,16 +177,17 @@ __global__ void __launch_bounds__(64) adain_affine_kernel(const float* __restric
   aff[((long)u * 2 + 1) * ld_aff + c] = sh;
 }
 
-// grid (ceil(ldy/64), row blocks of 64, n_utt); block 256 = 16 float4 columns x 16 row lanes.
+// grid (ceil(ldy/64), row blocks of rb, n_utt); block 256 = 16 float4 columns x 16 row lanes.  rb = 64, or 256 for large batches (the
+// per-block merge of the chunk statistics is then paid once per 64 KB instead of once per 16 KB of rows).
 // snake: y = v + sin^2(alpha*v)/alpha (AdaptiveGeneratorBlock, models/ada_norm.py:114,117) when alpha != null.
 __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy, int C,
                                                           const int* __restrict__ seg_off, const float* __restrict__ part, int ldp, int nchunk,
                                                           const float* __restrict__ gb, int ld_gb, int gcol0, float eps, int act,
-                                                          const float* __restrict__ alpha, int out16) {
+                                                          const float* __restrict__ alpha, int out16, int rb) {
   // out16: 0 = fp32 rows; PREC_BF16 / PREC_F16 = Y is a 16-bit row buffer (ldy in elements) read by the next contraction
   const int u = blockIdx.z;
   const int lo = seg_off[u], hi = seg_off[u + 1];
-  const int r0 = lo + blockIdx.y * 64;
+  const int r0 = lo + blockIdx.y * rb;
   if (r0 >= hi) return;
   // the block's 64 channels: one thread per channel merges the chunk statistics, result shared through LDS
   __shared__ float s_sc[64], s_sh[64], s_al[64];
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
     sh[k] = s_sh[cl + k];
     al[k] = s_al[cl + k];
   }
-  const int rend = min(hi, r0 + 64);
+  const int rend = min(hi, r0 + rb);
   for (int r = r0 + (threadIdx.x >> 4); r < rend; r += 16) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < C) {

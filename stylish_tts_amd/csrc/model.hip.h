@@ -855,8 +855,9 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
                      int gcol0, int act, const float* alpha, float* part, int out16 = 0) {
   const int nchunk = ceil_div(s.max_len(), kStatChunk), ldp = round_up(C, 32);
   STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk);
-  STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C * 4 + ldy * (out16 ? 2 : 4)), adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), 64), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
-                     part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha, out16);
+  const int rb = (long)ceil_div(ldy, 64) * ceil_div(s.rows(), 64) >= 4096 ? 256 : 64;  // rows per block
+  STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C * 4 + ldy * (out16 ? 2 : 4)), adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), rb), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
+                     part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha, out16, rb);
   STTS_HIP(hipGetLastError());
   return 0;
 }

@@ -100,13 +100,20 @@ __global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0,
       const double rad = ph0 + prefix[lo + j] + (double)(i + 1) * ((double)f / (double)kSampleRate);
       const float nh = (kSampleRate * 0.5f) / f;
       const float amp = 0.1f * sqrtf(2.0f / nh);
+      // sin(2 pi rad k), k = 1..K (generator.py:309-310 evaluates each in fp64 and rounds to fp32): 1-periodic in rad, so with
+      // theta = 2 pi frac(rad) the harmonics are sin(k theta) - one fp64 sincos and the three-term recurrence
+      // sin((k+1) theta) = 2 cos(theta) sin(k theta) - sin((k-1) theta), whose error (<= k^2 ulp64 ~ 3e-14 at k = 16) is far below
+      // both the fp32 rounding that follows and the reference's own rounding of the product 2 pi rad k (~3e-11 late in a 10-s utterance)
+      double s1, c1;
+      sincospi(2.0 * (rad - floor(rad)), &s1, &c1);
+      const double tc = 2.0 * c1;
+      double sp = 0.0, sk = s1;
       float acc = 0.f;
       for (int k = 1; k <= K; ++k) {
-        if (f * (float)k <= kSampleRate * 0.5f) {
-          double t = rad * (double)k;
-          t -= floor(t);  // sin(2*pi*t) is 1-periodic; reduce in fp64 before the evaluation
-          acc += (float)sin(6.283185307179586476925286766559 * t);
-        }
+        if (f * (float)k <= kSampleRate * 0.5f) acc += (float)sk;
+        const double nx = tc * sk - sp;
+        sp = sk;
+        sk = nx;
       }
       val += amp * acc;
     }
