@@ -415,6 +415,8 @@ int stts_profile_report(void* stream, char* json, size_t cap) {
     float t = 0;
     STTS_HIP(hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]));
     const ProfRec& r = p.recs[i];
+    if (getenv("STTS_PROF_DUMP"))  // diagnostics: every launch in issue order
+      fprintf(stderr, "[prof] %4zu %-28s %9.2f us %10.3f GFLOP (%.3f executed) %9.3f MB\n", i, r.name, 1e3 * t, r.flops * 1e-9, r.exec_flops * 1e-9, r.bytes * 1e-6);
     if (!agg.count(r.name)) order.push_back(r.name);
     Agg& g = agg[r.name];
     g.kind = r.kind;

@@ -160,10 +160,10 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, boo
           bool X16 = false>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
   static_assert(!(XAFF && GLDS), "the input affine lives on the register staging path");
-  static_assert(!X16 || (PREC != PREC_F32 && !XAFF && !GLDS && EPI == EPI_STORE), "16-bit activation rows: 16-bit operand modes, plain staging, store epilogue");
+  static_assert(!X16 || (PREC != PREC_F32 && !XAFF && EPI == EPI_STORE), "16-bit activation rows: 16-bit operand modes, store epilogue");
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
   constexpr bool B16 = PREC != PREC_F32;
-  static_assert(!(B16 && GLDS), "16-bit operands use the register staging path");
+  static_assert(!(B16 && GLDS) || X16, "LDS-DMA staging of 16-bit operands needs 16-bit activation rows (nothing converts on the way)");
   static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
   constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
   constexpr int TR = WR / 32, TC = WC / 32;
@@ -172,8 +172,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   static_assert(WR % 32 == 0 && WC % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert((X16 || (BN * 8) % NT == 0) && (B16 || (BM * 8) % NT == 0), "tile loads must divide over the block");
   static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
-  // two stages of [X rows | W rows] x 32 channels (16-bit operands: half of it; the K-group reduction of KSPLIT = 2 needs the full size)
-  __shared__ f32x4 lds[2 * (BN + BM) * ((B16 && KSPLIT == 1) ? 4 : 8)];
+  // two stages of [X rows | W rows] x 32 channels (16-bit operands: half of it; the K-group reduction of KSPLIT = 2 needs the full
+  // size); the 16-bit LDS-DMA path keeps three stages so that tiles are requested two iterations ahead
+  constexpr int NSTAGE = (B16 && GLDS) ? 3 : 2;
+  __shared__ f32x4 lds[NSTAGE * (BN + BM) * ((B16 && KSPLIT == 1) ? 4 : 8)];
 
   // XCD-aware block -> tile map (guide T1; speed only, any placement is correct): workgroups are dealt round-robin
   // over the 8 XCDs, each with its own L2.  Re-number them so that one XCD works through a CONTIGUOUS range of
@@ -455,15 +457,18 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     const f32x4* Ws = Xs + BN * 4;
     const int slot = 2 * kk + lh;
     f32x4 xa[TR], wb[TC];
+    const bool nord = ablate(32);  // timing-only ablation: operands are not read from LDS
 #pragma unroll
     for (int i = 0; i < TR; ++i) {
       const int r = wn * WR + i * 32 + l31;
-      xa[i] = Xs[r * 4 + (slot ^ ((r >> 2) & 3))];
+      if (!nord) xa[i] = Xs[r * 4 + (slot ^ ((r >> 2) & 3))];
+      else xa[i] = f32x4{(float)r, (float)kk, 0.f, 0.f};
     }
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
       const int c = wm * WC + j * 32 + l31;
-      wb[j] = Ws[c * 4 + (slot ^ ((c >> 2) & 3))];
+      if (!nord) wb[j] = Ws[c * 4 + (slot ^ ((c >> 2) & 3))];
+      else wb[j] = f32x4{(float)c, (float)kk, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < TR; ++i)
@@ -476,61 +481,136 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     // no ds_write, no mid-loop waits).  The destination is lane-linear, so the 16-byte-slot swizzle is applied to the
     // SOURCE slot each lane fetches (guide 5.4 rule 21); rows outside the utterance fetch from a page of zeros.
     static_assert(KSPLIT == 1, "GLDS path is single K-group");
-    constexpr int NW = NT / 64, NI = (BN + BM) / 8;  // wave-instructions per tile
-    static_assert(NI % NW == 0, "tile rows must divide over the waves");
-    const int wv = tid >> 6;
-    auto issue = [&](int b) {
-      const int shift = (tap - g_pad) * g_dil;
-      const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + chunk * 32);
-      const char* wb = reinterpret_cast<const char*>(gW + tap * g_kc + chunk * 32);
-      const int wrow = g_ntaps * g_kc;
+    if constexpr (B16) {
+      // 16-bit rows (64 bytes per tile row): one wave-instruction = 16 tile rows; three stages, tile it+2 is requested while tile it is
+      // multiplied, and the wait before the barrier leaves that newest tile's requests in flight (vmcnt retires in order)
+      constexpr int NW = NT / 64, NI = (BN + BM) / 16, PER = NI / NW;
+      static_assert(NI % NW == 0 && BN % 16 == 0, "tile rows must divide over the waves");
+      const int wv = tid >> 6;
+      auto issue = [&](int b) {
+        const int shift = (tap - g_pad) * g_dil;
+        const char* xb = reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(gX) + (long)lo * g_ldx + chunk * 32);
+        const char* wb = reinterpret_cast<const char*>(gW16 + tap * g_kc + chunk * 32);
+        const int wrow = g_ntaps * g_kc;
 #pragma unroll
-      for (int q = 0; q < NI / NW; ++q) {
-        const int inst = wv + q * NW;             // 8-row group of the combined [X rows | W rows] tile
-        const int trow = inst * 8 + (lane >> 3);  // row in the combined tile
-        const char* src;
-        if (inst < BN / 8) {                      // wave-uniform
-          const int r = trow;
-          const int sslot = (lane & 7) ^ ((r >> 1) & 7);
-          const int rel = rel0 + r + shift;
-          const bool ok = rel >= 0 && rel < len;
-          src = ok ? xb + (unsigned)((rel * g_ldx + sslot * 4) * 4) : reinterpret_cast<const char*>(a.zeros);
-        } else {
-          const int n = trow - BN;
-          const int sslot = (lane & 7) ^ ((n >> 1) & 7);
-          src = wb + (unsigned)((n * wrow + sslot * 4) * 4);
+        for (int q = 0; q < PER; ++q) {
+          const int inst = wv + q * NW;              // 16-row group of the combined [X rows | W rows] tile
+          const int trow = inst * 16 + (lane >> 2);  // row in the combined tile
+          const char* src;
+          if (inst < BN / 16) {                      // wave-uniform
+            const int r = trow;
+            const int sslot = (lane & 3) ^ ((r >> 2) & 3);
+            const int rel = rel0 + r + shift;
+            const bool ok = rel >= 0 && rel < len;
+            src = ok ? xb + (unsigned)((rel * g_ldx + sslot * 8) * 2) : reinterpret_cast<const char*>(a.zeros);
+          } else {
+            const int n = trow - BN;
+            const int sslot = (lane & 3) ^ ((n >> 2) & 3);
+            src = wb + (unsigned)((n * wrow + sslot * 8) * 2);
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(lds + b * (BN + BM) * 4 + inst * 64), 16, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + b * (BN + BM) * 8 + inst * 64), 16, 0, 0);
+        const bool wrapt1 = tap + 1 >= g_ntaps;
+        const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
+        const bool last = wrapt && (!MSEG || s + 1 >= nseg);
+        tap = last ? tap : (wrapt1 ? 0 : tap + 1);
+        chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
+        if constexpr (MSEG) {
+          if (wrapt && !last) {
+            ++s;
+            const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
+            gX = xbase(n);
+            gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+            g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+          }
+        }
+      };
+      auto wait_all_but_newest = [&]() {
+        static_assert(PER >= 1 && PER <= 6, "vmcnt immediate");
+        if constexpr (PER == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if constexpr (PER == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      };
+      issue(0);
+      issue(1);  // (the cursor re-issues the last tile once it runs off the end: harmless, nobody multiplies it)
+      wait_all_but_newest();
+      __syncthreads();
+      stamp(1);
+      int cur = 0, nxt = 2;
+      for (int it = 0; it < total; ++it) {
+        if (!ablate(8)) issue(nxt);  // tile it+2 -> the stage tile it-1 was read from (every wave has passed the barrier since)
+        mma_step16(cur, 0);
+        mma_step16(cur, 1);
+        wait_all_but_newest();       // tile it+1 has landed (this wave's share; the barrier covers the others')
+        if (!ablate(2)) __syncthreads();
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
       }
-      // advance the cursor (same order as the register path)
-      const bool wrapt1 = tap + 1 >= g_ntaps;
-      const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
-      const bool last = wrapt && (s + 1 >= nseg);
-      tap = last ? tap : (wrapt1 ? 0 : tap + 1);
-      chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
-      if (wrapt && !last) {
-        ++s;
-        const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
-        gX = xbase(n);
-        gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
-        if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
-        g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
-      }
-    };
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-      issue((it + 1) & 1);  // tile it+1 (the cursor re-issues the last tile at the end: harmless, nobody reads it)
-      const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
-      const f32x4* Ws = Xs + BN * 8;
-      mma_step(Xs, Ws, 0);
-      mma_step(Xs, Ws, 1);
-      mma_step(Xs, Ws, 2);
-      mma_step(Xs, Ws, 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead requests before the stages are reused / the block ends
+      __syncthreads();
+      stamp(2);
+    } else {
+        static_assert(KSPLIT == 1, "GLDS path is single K-group");
+      constexpr int NW = NT / 64, NI = (BN + BM) / 8;  // wave-instructions per tile
+      static_assert(NI % NW == 0, "tile rows must divide over the waves");
+      const int wv = tid >> 6;
+      auto issue = [&](int b) {
+        const int shift = (tap - g_pad) * g_dil;
+        const char* xb = reinterpret_cast<const char*>(gX + (long)lo * g_ldx + chunk * 32);
+        const char* wb = reinterpret_cast<const char*>(gW + tap * g_kc + chunk * 32);
+        const int wrow = g_ntaps * g_kc;
+  #pragma unroll
+        for (int q = 0; q < NI / NW; ++q) {
+          const int inst = wv + q * NW;             // 8-row group of the combined [X rows | W rows] tile
+          const int trow = inst * 8 + (lane >> 3);  // row in the combined tile
+          const char* src;
+          if (inst < BN / 8) {                      // wave-uniform
+            const int r = trow;
+            const int sslot = (lane & 7) ^ ((r >> 1) & 7);
+            const int rel = rel0 + r + shift;
+            const bool ok = rel >= 0 && rel < len;
+            src = ok ? xb + (unsigned)((rel * g_ldx + sslot * 4) * 4) : reinterpret_cast<const char*>(a.zeros);
+          } else {
+            const int n = trow - BN;
+            const int sslot = (lane & 7) ^ ((n >> 1) & 7);
+            src = wb + (unsigned)((n * wrow + sslot * 4) * 4);
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(lds + b * (BN + BM) * 8 + inst * 64), 16, 0, 0);
+        }
+        // advance the cursor (same order as the register path)
+        const bool wrapt1 = tap + 1 >= g_ntaps;
+        const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
+        const bool last = wrapt && (s + 1 >= nseg);
+        tap = last ? tap : (wrapt1 ? 0 : tap + 1);
+        chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
+        if (wrapt && !last) {
+          ++s;
+          const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
+          gX = xbase(n);
+          gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+          if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
+          g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+        }
+      };
+      issue(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      for (int it = 0; it < total; ++it) {
+        issue((it + 1) & 1);  // tile it+1 (the cursor re-issues the last tile at the end: harmless, nobody reads it)
+        const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
+        const f32x4* Ws = Xs + BN * 8;
+        mma_step(Xs, Ws, 0);
+        mma_step(Xs, Ws, 1);
+        mma_step(Xs, Ws, 2);
+        mma_step(Xs, Ws, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
     }
   } else {
   gload(rsA);  // tile 0
@@ -551,8 +631,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     if constexpr (B16) {
       if constexpr (KSPLIT == 1) {
         mma_step16(it & 1, 0);
-        lstore(nset, (it + 1) & 1);
-        gload(nset);
+        if (!ablate(4)) lstore(nset, (it + 1) & 1);
+        if (!ablate(8)) gload(nset);
         mma_step16(it & 1, 1);
       } else {
         mma_step16(it & 1, kg);
@@ -630,41 +710,72 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       stamp_end();
       return;
     }
+    // Uniform (scalar) base pointers at the tile's first row and column + 32-bit per-lane element offsets: a store is one vector
+    // add and a saddr-form instruction, and the epilogue keeps few enough registers live next to the accumulators (the 256 x 256
+    // tile spilled 290 of them with per-element 64-bit addresses: its epilogue took 42 us of a 228 us block).
+    const bool hasR = a.R != nullptr, hasY = a.Y != nullptr, hasSS = a.sumsq_part != nullptr;
+    bool hasY16 = false;
+    if constexpr (B16) hasY16 = a.Y16 != nullptr;
+    const int act = a.act;
+    const float alpha = a.alpha;
+    float* const Yb = hasY ? a.Y + (long)row0 * a.ldy + a.ycol0 + m0 : nullptr;
+    const float* const Rb = hasR ? a.R + (long)row0 * a.ldr + a.rcol0 + m0 : nullptr;
+    unsigned short* const Y16b = hasY16 ? a.Y16 + (long)row0 * a.ldy16 + a.ycol16 + m0 : nullptr;
+    const int rlane = wn * WR + 4 * lh, clane = wm * WC + l31;  // + i * 32 + (r & 3) + 8 * (r >> 2) ; + j * 32
+    // running element offsets of this lane's current row; consecutive accumulator elements are 1 row apart, or 5 (r = 3 -> 4, 7 -> 8,
+    // 11 -> 12, and 15 -> 0 of the next 32-row tile: 27 -> 32), so the whole wave tile is walked with two uniform steps per buffer
+    unsigned oy = (unsigned)(rlane * a.ldy + clane), orr = (unsigned)(rlane * a.ldr + clane), o16 = (unsigned)(rlane * a.ldy16 + clane);
+    const unsigned sy1 = (unsigned)a.ldy, sy5 = 5u * sy1, sr1 = (unsigned)a.ldr, sr5 = 5u * sr1, s161 = (unsigned)a.ldy16, s165 = 5u * s161;
+    float bv[TC];
+    bool nok[TC];
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
-      const int n = m0 + wm * WC + j * 32 + l31;
-      const float bv = a.bias ? a.bias[n] : 0.0f;
-      const bool nok = n < a.N;
+      const int n = m0 + clane + j * 32;
+      bv[j] = a.bias ? a.bias[n] : 0.0f;
+      nok[j] = n < a.N;
+    }
 #pragma unroll
-      for (int i = 0; i < TR; ++i) {
-        float ss = 0.0f;
+    for (int i = 0; i < TR; ++i) {
+      float ss[TC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = wn * WR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float v = act_apply(acc[i][j][r] + bv, a.act);
-          if (rl < nvalid && nok) {
-            const long grow = row0 + rl;
-            if (a.R) v += a.R[grow * a.ldr + a.rcol0 + n];
-            v *= a.alpha;
-            if (a.Y) a.Y[grow * a.ldy + a.ycol0 + n] = v;
+      for (int j = 0; j < TC; ++j) ss[j] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = i * 32 + (r & 3) + 8 * (r >> 2);  // compile-time row of this element inside the wave tile
+        const bool rok = rlane + dr < nvalid;
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+          float v = act_apply(acc[i][j][r] + bv[j], act);
+          if (rok && nok[j]) {
+            if (hasR) v += Rb[orr + j * 32];
+            v *= alpha;
+            if (hasY) Yb[oy + j * 32] = v;
             if constexpr (B16) {
-              if (a.Y16) {
-                if constexpr (PREC == PREC_BF16) reinterpret_cast<__bf16*>(a.Y16)[grow * a.ldy16 + a.ycol16 + n] = (__bf16)v;
-                else reinterpret_cast<_Float16*>(a.Y16)[grow * a.ldy16 + a.ycol16 + n] = (_Float16)v;
+              if (hasY16) {
+                if constexpr (PREC == PREC_BF16) reinterpret_cast<__bf16*>(Y16b)[o16 + j * 32] = (__bf16)v;
+                else reinterpret_cast<_Float16*>(Y16b)[o16 + j * 32] = (_Float16)v;
               }
             }
-            ss += v * v;
+            ss[j] += v * v;
           }
         }
-        if (a.sumsq_part) {
-          ss += __shfl_xor(ss, 32, 64);
+        const bool big = (r & 3) == 3;
+        oy += big ? sy5 : sy1;
+        orr += big ? sr5 : sr1;
+        o16 += big ? s165 : s161;
+      }
+      if (hasSS) {
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+          float t2 = ss[j] + __shfl_xor(ss[j], 32, 64);
           const int sub = by * (BN / 32) + (wn * TR + i);  // 32-row sub-tile of the utterance; the consumer reads ceil(len / 32) of them
-          if (lh == 0 && nok && sub * 32 < hi - lo) {
+          if (lh == 0 && nok[j] && sub * 32 < hi - lo) {
             const long t = (long)utt * a.ss_stride + sub;
-            a.sumsq_part[t * a.ld_ss + n] = ss;
+            a.sumsq_part[t * a.ld_ss + m0 + clane + j * 32] = t2;
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);  // one 32-row band at a time: keeps the temporaries of 8 tiles from piling up
     }
   } else if constexpr (EPI == EPI_SPLIT_ACC) {
 #pragma unroll
@@ -875,6 +986,11 @@ template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = 
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
   if (a.compact) grid = dim3(npad / BM, a.tiles_y, a.ksplit > 1 ? a.ksplit : 1);
+  if constexpr (GL && PR != PREC_F32) {  // 16-bit LDS-DMA tiles: 16-bit activation rows + store epilogue only (the dispatcher guarantees it)
+    if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, true, PR, false, false, true>), grid, block, st, e0, e1, a);
+    else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, true, PR, false, true, true>), grid, block, st, e0, e1, a);
+    return;
+  } else
   switch (epi) {
     case EPI_STORE:
       if constexpr (!GL && PR != PREC_F32 && KS == 1) {
@@ -995,8 +1111,9 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   }
   STTS_CHECK(!(a.x16 && (tile == 8 || tile == 11 || tile == 13 || a.xaff)), "conv_gemm: 16-bit activation rows need a plain register-staged tile");
   STTS_CHECK(!((tile == 14 || tile == 15) && (a.prec == PREC_F32 || epi != EPI_STORE)), "conv_gemm: tiles 14 / 15 are for 16-bit operand store launches");
-  STTS_CHECK(tile != 14 || npad % 256 == 0, "conv_gemm: tile 14 needs cout padded to 256");
-  const int bn = (tile == 14 || tile == 15) ? 256 : (tile == 5 || tile == 8 || tile == 11) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
+  STTS_CHECK(!((tile == 16 || tile == 17) && (a.prec == PREC_F32 || epi != EPI_STORE || !a.x16)), "conv_gemm: tiles 16 / 17 are for 16-bit activation rows, store epilogue");
+  STTS_CHECK((tile != 14 && tile != 16) || npad % 256 == 0, "conv_gemm: tiles 14 / 16 need cout padded to 256");
+  const int bn = (tile >= 14 && tile <= 17) ? 256 : (tile == 5 || tile == 8 || tile == 11) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
   if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
   if (tile == 8) {
     plan.full_rt = row_tiles(bn);
@@ -1006,6 +1123,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   //  configuration plateaus at ~80 % matrix-pipe occupancy)
   GemmArgs as = a;
   as.n_utt = n_utt;
+  if (!as.zeros) as.zeros = zero_page();
   as.compact = a.seg_host != nullptr;  // grid.y = the row tiles that exist; needed for tile ranges and for balanced XCDs
   // Block-level split-K for launches that cannot fill the chip (phoneme-rate layers, B = 1): one wave's MFMA chain over
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
@@ -1058,6 +1176,12 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
           break;
         case 15:
           if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+          break;
+        case 16:  // tiles 14 / 15 with LDS-DMA staging (global_load_lds_dwordx4, three stages): 16-bit activation rows only
+          if constexpr (PR != PREC_F32) launch_cfg<256, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+          break;
+        case 17:
+          if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
           break;
         case 11:
           if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves

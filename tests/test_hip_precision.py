@@ -66,6 +66,13 @@ def rounded_oracle():
         (512, 1536, 1, 1, [700, 1], 114),
         (578, 512, 3, 1, [260, 255, 257, 31], 115),
         (1024, 256, 7, 1, [513], 115),
+        # ... and the LDS-DMA (global_load_lds) variants of the 256-row tiles: three stages, ragged tails, several K segments' worth of taps
+        (768, 1024, 7, 1, [300, 517, 2], 116),
+        (512, 1536, 1, 1, [700, 1], 116),
+        (32, 256, 1, 1, [5, 256], 116),
+        (578, 512, 3, 1, [260, 255, 257, 31], 117),
+        (1024, 256, 7, 1, [513], 117),
+        (64, 130, 7, 3, [77, 5], 117),
     ],
 )
 def test_conv1d_16bit_matches_rounded_oracle(hip32, rounded_oracle, prec, cin, cout, k, dil, lengths, tile):

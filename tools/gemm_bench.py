@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stylish_tts_amd import _lib
-lib = C.CDLL(_lib.LIB_PATH)
+lib = C.CDLL(os.environ.get("STTS_LIB", _lib.LIB_PATH))  # STTS_LIB: e.g. a -DSTTS_GEMM_TRACE build (ablation bits of TUNE)
 lib.stts_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
 torch.zeros(1).cuda()
 shapes = [  # name, cin, cout, k
