@@ -25,7 +25,9 @@ for name, cin, cout, k in shapes:
         ms = C.c_double()
         nu, rows = (1, 4096) if name.startswith("square") else (B, T4)
         rc = lib.stts_bench_gemm(None, nu, rows, cin, cout, k, tile, 10, C.byref(ms), int(os.environ.get('TUNE', 0)))
-        assert rc == 0
+        if rc != 0:  # this tile does not apply to the shape (e.g. 256-column tiles need cout padded to 256)
+            line += f"  tile{tile}:      n/a            "
+            continue
         fl = 2.0 * nu * rows * cout * cin * k
         line += f"  tile{tile}: {ms.value*1e3:8.1f} us {fl/ms.value/1e9:6.1f} TF"
     print(line, flush=True)
