@@ -751,3 +751,143 @@ def cfm_solve_euler(z, n_timesteps, estimator, temperature=1.0):
         if k < n:
             dt = F32(t_span[k + 1] - t)
     return x
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CfmMelDecoder._forward: the XUT estimator of the flow-matching mel decoder
+# (models/cfm/cfm_mel_decoder.py:190-398, models/xut/*.py).  Inference mode: no TREAD token dropout (cfm_mel_decoder.py:349).
+# The one RNG draw inside the estimator (SineGenerator's additive noise, cfm_mel_decoder.py:99) is an input here.
+# ----------------------------------------------------------------------------------------------------------------------
+def mish(x):
+    """F.mish = x * tanh(softplus(x)), softplus with torch's threshold 20."""
+    x64 = x.astype(np.float64)
+    sp = np.where(x64 > 20.0, x64, np.log1p(np.exp(np.minimum(x64, 20.0))))
+    return (x64 * np.tanh(sp)).astype(F32)
+
+
+def rms_norm(x, wt, eps=1e-6):
+    """F.rms_norm over the last axis (xut/norm.py:25-40, offset 0)."""
+    x64 = x.astype(np.float64)
+    return (x64 / np.sqrt((x64 * x64).mean(-1, keepdims=True) + eps) * wt).astype(F32)
+
+
+def torch_linspace(start, end, n):
+    """torch.linspace in fp32: start + i * step below the midpoint, end - (n - 1 - i) * step above it."""
+    if n == 1:
+        return np.array([start], F32)
+    step = (F32(end) - F32(start)) / F32(n - 1)
+    i = np.arange(n)
+    return np.where(i < n // 2, F32(start) + i.astype(F32) * step, F32(end) - (n - 1 - i).astype(F32) * step).astype(F32)
+
+
+def interpolate_nearest(a, n):
+    """F.interpolate(a[:, None], n) (default mode 'nearest'): src = min(floor(dst * (L / n)), L - 1), scale in fp32."""
+    L = a.shape[-1]
+    if L == n:
+        return a
+    scale = F32(L) / F32(n)
+    idx = np.minimum(np.floor(np.arange(n, dtype=F32) * scale).astype(np.int64), L - 1)
+    return a[..., idx]
+
+
+def sine_generator(f0, noise, merge_w, sr=24000.0, sine_amp=0.1, noise_std=0.003):
+    """SineGenerator.forward with harmonic_num = 0 (cfm_mel_decoder.py:54-104): f0 [B, n, 1]; `noise` replaces randn_like.
+    With one component the random initial phase is zeroed (:68).  torch.cumsum of fp32 on the CPU accumulates in double."""
+    rad = np.mod(f0.astype(F32) / F32(sr), F32(1.0)).astype(F32)
+    tmp = np.mod(np.cumsum(rad.astype(np.float64), axis=1).astype(F32), F32(1.0))
+    shift = np.zeros_like(rad)
+    shift[:, 1:] = ((tmp[:, 1:] - tmp[:, :-1]) < 0).astype(F32) * F32(-1.0)
+    phase = np.cumsum((rad + shift).astype(np.float64), axis=1).astype(F32)
+    sines = np.sin(((phase * F32(2.0)) * F32(np.pi)).astype(F32).astype(np.float64)).astype(F32)
+    uv = (f0 > 0).astype(F32)
+    noise_amp = uv * F32(noise_std) + (1 - uv) * F32(sine_amp) / F32(3.0)
+    sw = (sines * F32(sine_amp)) * uv + noise_amp * noise
+    return np.tanh((sw * merge_w.reshape(())).astype(np.float64)).astype(F32)
+
+
+def axial_rope(x, pos, log_freqs):
+    """AxialRoPE.forward with pos_dim = 1 (xut/axial_rope.py:10-29,122-149): x [B, H, n, d], pos [B, n, 1], log_freqs [H, d/2, 1];
+    angle[b, h, n, 2 i] = angle[.., 2 i + 1] = pos * exp(log_freqs[h, i]); pairs (x0, x1) -> x * cos + (-x1, x0) * sin."""
+    fr = (pos[:, :, None, None, :] * np.exp(log_freqs.astype(F32))[None, None]).astype(F32)  # [B, n, H, d/2, 1]
+    fr = np.repeat(fr.reshape(fr.shape[0], fr.shape[1], fr.shape[2], -1), 2, axis=-1).transpose(0, 2, 1, 3)  # [B, H, n, d]
+    rot = np.stack((-x[..., 1::2], x[..., 0::2]), axis=-1).reshape(x.shape)
+    return (x * np.cos(fr) + rot * np.sin(fr)).astype(F32)
+
+
+def sdpa(q, k, v):
+    """F.scaled_dot_product_attention without mask: softmax(q k^T / sqrt(d)) v."""
+    s = np.matmul(q.astype(np.float64), k.astype(np.float64).transpose(0, 1, 3, 2)) / np.sqrt(q.shape[-1])
+    s = np.exp(s - s.max(-1, keepdims=True))
+    return np.matmul(s / s.sum(-1, keepdims=True), v.astype(np.float64)).astype(F32)
+
+
+def xut_block(x, ctx, pos, shared, w: W, p: str, head_dim=64):
+    """TransformerBlock.forward with shared AdaLN (xut/transformer.py:54-79, xut/adaln.py:19-27, xut/attention.py:29-67,91-131,
+    xut/layers.py:23-29).  shared = [(scale, shift, gate)] * 3 for attn / xattn / mlp, each [B, 1, dim]."""
+    B, n, dim = x.shape
+    H = dim // head_dim
+
+    def adaln(x, norm_p, s):
+        return (rms_norm(x, w[norm_p + ".norm.weight"]) * (s[0] + F32(1.0)) + s[1]).astype(F32), (s[2] + F32(1.0)).astype(F32)
+
+    def heads(t, m):
+        return t.reshape(B, m, H, head_dim).transpose(0, 2, 1, 3)
+
+    h, gate = adaln(x, p + ".attn_pre_norm", shared[0])
+    q, k, v = np.split(linear(h, w[p + ".attn.qkv.weight"]), 3, axis=-1)
+    fr = w[p + ".attn.rope.freqs"]
+    o = sdpa(axial_rope(heads(q, n), pos, fr), axial_rope(heads(k, n), pos, fr), heads(v, n)).transpose(0, 2, 1, 3).reshape(B, n, dim)
+    # (transformer.py:67-68 rebinds x to the NORMALISED tensor before the residual add: x = adaln(x) + attn(adaln(x)) * gate)
+    x = (h + linear(o, w[p + ".attn.out.weight"], w[p + ".attn.out.bias"]) * gate).astype(F32)
+    if ctx is not None:
+        h, gate = adaln(x, p + ".xattn_pre_norm", shared[1])
+        m = ctx.shape[1]
+        q = linear(h, w[p + ".xattn.q.weight"])
+        k, v = np.split(linear(ctx, w[p + ".xattn.kv.weight"]), 2, axis=-1)
+        fr = w[p + ".xattn.rope.freqs"]
+        o = sdpa(axial_rope(heads(q, n), pos, fr), axial_rope(heads(k, m), pos, fr), heads(v, m)).transpose(0, 2, 1, 3).reshape(B, n, dim)
+        x = (h + linear(o, w[p + ".xattn.out.weight"], w[p + ".xattn.out.bias"]) * gate).astype(F32)
+    h, gate = adaln(x, p + ".mlp_pre_norm", shared[2])
+    x1, x2 = np.split(linear(h, w[p + ".mlp.w12.weight"], w[p + ".mlp.w12.bias"]), 2, axis=-1)
+    return (h + linear((silu(x1) * x2).astype(F32), w[p + ".mlp.w3.weight"], w[p + ".mlp.w3.bias"]) * gate).astype(F32)
+
+
+def cfm_mel_decoder_forward(x, asr, f0, n_curve, spk, t, sine_noise, w: W, dims):
+    """CfmMelDecoder._forward (cfm_mel_decoder.py:318-398), eval mode.  x [B, feat, n], asr [B, asr_dim, n], f0 / n_curve [B, L],
+    spk [B, spk_dim], t [B], sine_noise [B, n, 1].  dims: depth, enc_blocks, dec_blocks, prev_depth, post_depth, head_dim."""
+    B, _, n = x.shape
+    xt = x.transpose(0, 2, 1).astype(F32)
+    asr_e = linear(mish(linear(asr.transpose(0, 2, 1), w["asr_emb.1.weight"], w["asr_emb.1.bias"])), w["asr_emb.3.weight"], w["asr_emb.3.bias"])
+    spk_e = linear(mish(linear(spk, w["spk_emb.0.weight"], w["spk_emb.0.bias"])), w["spk_emb.2.weight"], w["spk_emb.2.bias"])
+    spk_e = np.repeat(spk_e[:, None, :], n, axis=1)
+    f0i = interpolate_nearest(f0, n)[:, :, None]
+    ni = interpolate_nearest(n_curve, n)[:, :, None]
+    src = sine_generator(f0i, sine_noise, w["m_source.1.merge.0.weight"])
+    har = np.concatenate([src, ni, np.repeat(t.reshape(B, 1, 1), n, axis=1)], axis=-1).astype(F32)  # [B, n, 3]
+    prior = conv1d(har.transpose(0, 2, 1), w["prior_generator.1.weight"], w["prior_generator.1.bias"], padding=3).transpose(0, 2, 1)
+    h = linear(np.concatenate([(xt + prior).astype(F32), asr_e, spk_e], axis=-1), w["in_proj.weight"], w["in_proj.bias"])
+    # TimestepEmbedding (xut/time_emb.py:24-31) on t [B, 1]
+    args = (F32(1000.0) * t.reshape(B, 1, 1).astype(F32)) * w["time_emb.freqs"].reshape(1, 1, -1)
+    t_emb = mish(linear(np.concatenate([np.cos(args), np.sin(args)], axis=-1).astype(F32), w["time_emb.proj.0.weight"], w["time_emb.proj.0.bias"]))
+
+    def shared(p):
+        y = layer_norm_last(t_emb, 1e-5) * w[p + ".0.weight"] + w[p + ".0.bias"]
+        y = linear(mish(linear(y.astype(F32), w[p + ".1.weight"], w[p + ".1.bias"])), w[p + ".3.weight"], w[p + ".3.bias"])
+        return np.split(y, 3, axis=-1)
+
+    sh = [shared("shared_adaln_attn"), shared("shared_adaln_xattn"), shared("shared_adaln_ffw")]
+    pos = np.repeat(torch_linspace(-1.0, 1.0, n)[None, :, None], B, axis=0)
+    hd = dims.get("head_dim", 64)
+    for i in range(dims["prev_depth"]):
+        h = xut_block(h, None, pos, sh, w, f"prev_tread_trns.blocks.{i}", hd)
+    self_ctx = []
+    for i in range(dims["depth"]):  # XUTBackBone.forward (xut/xut.py:183-216)
+        for j in range(dims["enc_blocks"]):
+            h = xut_block(h, None, pos, sh, w, f"backbone.enc_blocks.{i}.{j}", hd)
+        self_ctx.append(h)
+    for i in range(dims["depth"]):
+        for j in range(dims["dec_blocks"]):
+            h = xut_block(h, self_ctx[-1] if j == 0 else None, pos, sh, w, f"backbone.dec_blocks.{i}.{j}", hd)
+    for i in range(dims["post_depth"]):
+        h = xut_block(h, None, pos, sh, w, f"post_tread_trns.blocks.{i}", hd)
+    return linear(h, w["out_proj.0.weight"], w["out_proj.0.bias"]).transpose(0, 2, 1).astype(F32)

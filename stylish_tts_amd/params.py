@@ -275,6 +275,56 @@ MODULE_SPECS = {
 }
 
 
+# CfmMelDecoder (models/cfm/cfm_mel_decoder.py:190-245; blocks: models/xut/transformer.py:9-51).  Dimensions are not in the model
+# YAML (the class is constructed with keyword defaults), so they travel as a plain dict.
+CFM_DEFAULT_DIMS = dict(feat_dim=80, asr_dim=768, spk_dim=1024, hidden_dim=256, emb_dim=256, depth=4, enc_blocks=1, dec_blocks=2,
+                        prev_depth=1, post_depth=3, head_dim=64)
+
+
+def xut_block_spec(p: str, dim: int, mlp: int, head_dim: int, cross: bool) -> Spec:
+    """TransformerBlock with shared AdaLN: SelfAttention [+ CrossAttention] + SwiGLU + RMSNorm weights (registration order)."""
+    heads = dim // head_dim
+    s: Spec = [(p + ".attn.qkv.weight", (3 * dim, dim), "w_qk"), (p + ".attn.out.weight", (dim, dim), "w_attn_o"), (p + ".attn.out.bias", (dim,), "b"),
+               (p + ".attn.rope.freqs", (heads, head_dim // 2, 1), "rope_f")]
+    if cross:
+        s += [(p + ".xattn.q.weight", (dim, dim), "w_qk"), (p + ".xattn.kv.weight", (2 * dim, dim), "w_qk"),
+              (p + ".xattn.out.weight", (dim, dim), "w_attn_o"), (p + ".xattn.out.bias", (dim,), "b"),
+              (p + ".xattn.rope.freqs", (heads, head_dim // 2, 1), "rope_f")]
+    s += [(p + ".mlp.w12.weight", (2 * mlp, dim), "w"), (p + ".mlp.w12.bias", (2 * mlp,), "b"),
+          (p + ".mlp.w3.weight", (dim, mlp), "w_small"), (p + ".mlp.w3.bias", (dim,), "b"),
+          (p + ".attn_pre_norm.norm.weight", (dim,), "ln_g"), (p + ".mlp_pre_norm.norm.weight", (dim,), "ln_g")]
+    if cross:
+        s.append((p + ".xattn_pre_norm.norm.weight", (dim,), "ln_g"))
+    return s
+
+
+def cfm_mel_decoder_spec(dims=None) -> Spec:
+    d = dict(CFM_DEFAULT_DIMS, **(dims or {}))
+    dim, emb, feat, mlp, hd = d["hidden_dim"], d["emb_dim"], d["feat_dim"], 4 * d["hidden_dim"], d["head_dim"]
+    s: Spec = [("time_emb.freqs", (1, dim // 2), "time_freqs")]
+    s += _linear("time_emb.proj.0", dim, dim)
+    s += _linear("asr_emb.1", 4 * emb, d["asr_dim"]) + _linear("asr_emb.3", emb, 4 * emb)
+    s += _linear("spk_emb.0", 4 * emb, d["spk_dim"]) + _linear("spk_emb.2", emb, 4 * emb)
+    s += [("m_source.1.merge.0.weight", (1, 1), "w")]
+    s += _conv("prior_generator.1", feat, 3, 7)
+    for i in range(d["depth"]):
+        for j in range(d["enc_blocks"]):
+            s += xut_block_spec(f"backbone.enc_blocks.{i}.{j}", dim, mlp, hd, False)
+    for i in range(d["depth"]):
+        for j in range(d["dec_blocks"]):
+            s += xut_block_spec(f"backbone.dec_blocks.{i}.{j}", dim, mlp, hd, j == 0)
+    s += _linear("in_proj", dim, feat + 2 * emb) + _linear("out_proj.0", feat, dim)
+    for nm in ("shared_adaln_attn", "shared_adaln_xattn", "shared_adaln_ffw"):
+        s += [(nm + ".0.weight", (dim,), "ln_g"), (nm + ".0.bias", (dim,), "ln_b")]
+        s += _linear(nm + ".1", 4 * dim, dim)
+        s += [(nm + ".3.weight", (3 * dim, 4 * dim), "w_small"), (nm + ".3.bias", (3 * dim,), "b")]  # zero-initialised in the reference (:262-277)
+    for i in range(d["prev_depth"]):
+        s += xut_block_spec(f"prev_tread_trns.blocks.{i}", dim, mlp, hd, False)
+    for i in range(d["post_depth"]):
+        s += xut_block_spec(f"post_tread_trns.blocks.{i}", dim, mlp, hd, False)
+    return s
+
+
 def module_spec(module: str, cfg) -> Spec:
     return MODULE_SPECS[module](cfg)
 
@@ -365,6 +415,11 @@ def synth_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0) ->
         v = 1.0 + 0.3 * u
     elif kind == "emb":
         v = u * np.sqrt(3.0) * (shape[1] ** -0.5)
+    elif kind == "rope_f":  # log-frequencies in [log pi, log 5 pi] (xut/axial_rope.py:110-116 initialises a linspace over that range)
+        v = np.log(np.pi) + 0.5 * (u + 1.0) * np.log(5.0)
+    elif kind == "time_freqs":  # the TimestepEmbedding buffer (xut/time_emb.py:14-22), formed in fp32 like torch does
+        half = shape[-1]
+        v = np.exp((np.float32(-np.log(10000.0)) * np.arange(half, dtype=np.float32) / np.float32(half)).astype(np.float32)).astype(np.float32)
     else:  # pragma: no cover
         raise ValueError(kind)
     return v.astype(np.float32).reshape(shape)

@@ -440,6 +440,50 @@ def cfm_golden():
     save("cfm_euler", **out)
 
 
+CFM_SMALL = dict(feat_dim=80, asr_dim=96, spk_dim=48, hidden_dim=128, emb_dim=64, depth=2, enc_blocks=1, dec_blocks=2, prev_depth=1, post_depth=1)
+
+
+def cfm_decoder_golden():
+    """CfmMelDecoder._forward and .forward (models/cfm/cfm_mel_decoder.py:318-413) with synthetic weights: the estimator alone
+    (one evaluation, B = 2) at the class defaults and at a small size, and the n-step Euler sampling through it (small size)."""
+    from stylish_tts.train.models.cfm.cfm_mel_decoder import CfmMelDecoder
+
+    out = {}
+    for tag, dims, B, n, L in (("default", dict(params.CFM_DEFAULT_DIMS), 2, 53, 27), ("small", dict(params.CFM_DEFAULT_DIMS, **CFM_SMALL), 2, 70, 70)):
+        m = CfmMelDecoder(feat_dim=dims["feat_dim"], asr_dim=dims["asr_dim"], spk_dim=dims["spk_dim"], hidden_dim=dims["hidden_dim"],
+                          emb_dim=dims["emb_dim"], xut_depth=dims["depth"], xut_enc_blocks=dims["enc_blocks"], xut_dec_blocks=dims["dec_blocks"],
+                          tread_config={"prev_trns_depth": dims["prev_depth"], "post_trns_depth": dims["post_depth"], "dropout_ratio": 0.5}).eval()
+        spec = params.cfm_mel_decoder_spec(dims)
+        sd = params.synth_state_dict(spec, SEED, prefix="cfm_mel_decoder.")
+        ref_sd = m.state_dict()
+        assert sorted(ref_sd.keys()) == sorted(sd.keys()), sorted(set(ref_sd) ^ set(sd))
+        for k, v in sd.items():
+            assert tuple(ref_sd[k].shape) == v.shape, (k, tuple(ref_sd[k].shape), v.shape)
+        m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
+        x = synth.normal(f"cfmd.{tag}.x", (B, dims["feat_dim"], n))
+        asr = synth.normal(f"cfmd.{tag}.asr", (B, dims["asr_dim"], n))
+        f0 = synth.pitch_curve(f"cfmd.{tag}.f0", B, L)
+        f0[:, L // 3 : L // 3 + 4] = 0.0  # an unvoiced stretch
+        nc = (synth.uniform(f"cfmd.{tag}.n", (B, L)) * 2 + 2).astype(np.float32)
+        spk = synth.normal(f"cfmd.{tag}.spk", (B, dims["spk_dim"]))
+        tt = np.array([0.3, 0.85][:B], np.float32)
+        nz = synth.normal(f"cfmd.{tag}.nz", (B, n, 1))
+        with torch.no_grad(), Replay(rand=[np.zeros((B, 1), np.float32)], randn_like=[nz]):
+            y = m._forward(t(x), t(asr), t(f0), t(nc), t(spk), t(tt))
+        out.update({f"{tag}_x": x, f"{tag}_asr": asr, f"{tag}_f0": f0, f"{tag}_n": nc, f"{tag}_spk": spk, f"{tag}_t": tt, f"{tag}_nz": nz, f"{tag}_y": y})
+        if tag == "small":  # the sampler: z is drawn by torch.rand inside forward (:402), then one estimator call (with its two draws) per step
+            steps = 4
+            z = synth.uniform("cfmd.z", (B, dims["feat_dim"], n))
+            nzs = [synth.normal(f"cfmd.nz{i}", (B, n, 1)) for i in range(steps)]
+            rand = [z]
+            for _ in range(steps):
+                rand.append(np.zeros((B, 1), np.float32))
+            with Replay(rand=rand, randn_like=nzs):
+                ys = m(t(asr), t(f0), t(nc), t(spk), steps, 0.9)
+            out.update(dict(sample_z=z, sample_y=ys, sample_steps=steps, sample_temperature=0.9, **{f"sample_nz{i}": a for i, a in enumerate(nzs)}))
+    save("cfm_decoder", **out)
+
+
 NARROW = {"decoder": {"hidden_dim": 384, "residual_dim": 32}, "generator": {"input_dim": 384, "hidden_dim": 384, "conv_intermediate_dim": 1152}}
 
 
@@ -531,11 +575,14 @@ if __name__ == "__main__":
         narrow_golden()
     elif "--only-cfm" in sys.argv:
         cfm_golden()
+    elif "--only-cfm-decoder" in sys.argv:
+        cfm_decoder_golden()
     elif "--only-text" in sys.argv:
         _ = text_golden()
     else:
         main()
         text_golden()
         cfm_golden()
+        cfm_decoder_golden()
         conv_stft_golden()
         narrow_golden()
