@@ -62,7 +62,8 @@ enum {
   STTS_W_PE_STYLE = 64,      /* pe_text_style_encoder                                      models/models.py:53-57 */
   STTS_W_PITCH_ENERGY = 128, /* pitch_energy_predictor.*                                   models/pitch_energy_predictor.py */
   STTS_W_FRAME_PATH = 7,
-  STTS_W_ALL = 255
+  STTS_W_ALL = 255,
+  STTS_W_CFM = 256           /* cfm_mel_decoder.* (finalized by stts_cfm_finalize, not part of STTS_W_ALL)  models/cfm/cfm_mel_decoder.py */
 };
 int stts_finalize_weights(stts_ctx* ctx, int which);
 /* Operand precision of the Conv1d / Linear contractions (call before the first stts_finalize_weights).
@@ -163,6 +164,24 @@ int stts_upsample4(stts_ctx* ctx, void* stream, int n_utt, const int32_t* off_T_
 /* One explicit-Euler update of the flow-matching sampler, x += dt * v over n floats
  * (models/cfm/cfm.py:65-84, CfmSampler.solve_euler: `x = x + dt * dphi_dt`). */
 int stts_euler_step(void* stream, float* x, const float* v, float dt, int64_t n);
+
+/* The estimator of that sampler in the reference: CfmMelDecoder._forward (models/cfm/cfm_mel_decoder.py:318-398; XUT transformer,
+ * models/xut/), inference mode.  Its dimensions are constructor keywords in the reference (:190-206), hence this struct.
+ * Weights: stts_load_weight(ctx, "cfm_mel_decoder.<state_dict key>", ...) then stts_cfm_finalize.
+ * One evaluation on a packed batch: x [rows, ld_x] time-major (feat_dim columns), asr [rows, ld_asr] (ld_asr a multiple of 32, pad
+ * columns finite), f0 / n_curve: per-utterance curves back to back with offsets curve_off (resampled to the utterance's frames by
+ * F.interpolate's nearest rule, :322-323), spk_emb [n_utt, spk_dim], t [n_utt], sine_noise [rows] = the one RNG draw inside the
+ * estimator (SineGenerator's additive noise, :99; the caller draws it), out [rows, ld_out] = dphi/dt.  All tensors on the device.
+ * Limits: <= 1024 frames per utterance (attention keys), SineGenerator without overtones (the reference's configuration). */
+typedef struct stts_cfm_dims {
+  int32_t feat_dim, asr_dim, spk_dim, hidden_dim, emb_dim, depth, enc_blocks, dec_blocks, prev_depth, post_depth, head_dim;
+} stts_cfm_dims;
+int stts_cfm_finalize(stts_ctx* ctx, const stts_cfm_dims* dims);
+size_t stts_cfm_workspace_bytes(const stts_ctx* ctx, int64_t rows, int n_utt);
+int stts_cfm_estimator(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ld_x,
+                       const float* asr, int ld_asr, const float* f0, const float* n_curve, const int32_t* curve_off_host,
+                       const int32_t* curve_off_dev, const float* spk_emb, const float* t, const float* sine_noise, float* out, int ld_out,
+                       void* workspace, size_t workspace_bytes);
 
 /* Layout bridge for the nn.Module shims: reference [B, C, T] (equal T) <-> time-major rows. */
 int stts_to_time_major(void* stream, const float* x_bct, int B, int C, int T, float* y, int ldy);

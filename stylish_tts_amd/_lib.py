@@ -25,6 +25,12 @@ class ModelDims(C.Structure):
     )]
 
 
+class CfmDims(C.Structure):
+    """include/stylish_hip.h: stts_cfm_dims (the constructor keywords of the reference's CfmMelDecoder)."""
+    _fields_ = [(n, C.c_int32) for n in ("feat_dim", "asr_dim", "spk_dim", "hidden_dim", "emb_dim", "depth", "enc_blocks", "dec_blocks",
+                                         "prev_depth", "post_depth", "head_dim")]
+
+
 def dims_from_config(cfg) -> ModelDims:
     g, te, du = cfg.generator, cfg.text_encoder, cfg.duration_predictor
     return ModelDims(
@@ -70,6 +76,9 @@ SIGNATURES = {
     "stts_set_precision": (_I, [_P, _I]),
     "stts_upsample4": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "stts_euler_step": (_I, [_P, _P, _P, C.c_float, C.c_int64]),
+    "stts_cfm_finalize": (_I, [_P, _P]),
+    "stts_cfm_workspace_bytes": (_SZ, [_P, _I64, _I]),
+    "stts_cfm_estimator": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _SZ]),
     "stts_to_time_major": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "stts_to_channel_major": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stts_conv_stft_transform": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I]),

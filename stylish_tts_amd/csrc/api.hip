@@ -1,6 +1,7 @@
 // extern "C" entry points declared in include/stylish_hip.h.  Single translation unit: hipcc compiles this file
 // (which includes every kernel header) into libstylish_hip.so for gfx950.
 #include "model.hip.h"
+#include "cfm.hip.h"
 
 using namespace stts;
 
@@ -201,6 +202,53 @@ int stts_euler_step(void* stream, float* x, const float* v, float dt, int64_t n)
   if (n) hipLaunchKernelGGL(euler_step_kernel, dim3((unsigned)std::min<int64_t>(4096, (n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x, v, dt, (long)n);
   STTS_HIP(hipGetLastError());
   return 0;
+  API_END
+}
+
+// ------------------------------------------------------------------------------------------------ CfmMelDecoder estimator (cfm.hip.h)
+int stts_cfm_finalize(stts_ctx* c, const stts_cfm_dims* dims) {
+  API_BEGIN
+  STTS_CHECK(c && dims, "null argument");
+  STTS_HIP(hipSetDevice(c->device));
+  free_component_allocs(c, STTS_W_CFM);
+  c->ready &= ~STTS_W_CFM;
+  CfmDims d;
+  d.feat = dims->feat_dim; d.asr = dims->asr_dim; d.spk = dims->spk_dim; d.hidden = dims->hidden_dim; d.emb = dims->emb_dim; d.depth = dims->depth;
+  d.enc_blocks = dims->enc_blocks; d.dec_blocks = dims->dec_blocks; d.prev_depth = dims->prev_depth; d.post_depth = dims->post_depth; d.head_dim = dims->head_dim;
+  auto m = std::make_shared<CfmModel>();
+  c->cur_tag = STTS_W_CFM;
+  const int rc = finalize_cfm(c, d, m.get());
+  c->cur_tag = 0;
+  if (rc) return rc;
+  c->cfm = m;
+  c->ready |= STTS_W_CFM;
+  STTS_HIP(hipDeviceSynchronize());
+  return 0;
+  API_END
+}
+
+size_t stts_cfm_workspace_bytes(const stts_ctx* c, int64_t rows, int n_utt) {
+  if (!c || !c->cfm) return 0;
+  return cfm_workspace_bytes(const_cast<stts_ctx*>(c), *static_cast<const CfmModel*>(c->cfm.get()), rows, n_utt);
+}
+
+int stts_cfm_estimator(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ld_x,
+                       const float* asr, int ld_asr, const float* f0, const float* n_curve, const int32_t* curve_off_host, const int32_t* curve_off_dev,
+                       const float* spk_emb, const float* t, const float* sine_noise, float* out, int ld_out, void* ws, size_t ws_bytes) {
+  API_BEGIN
+  STTS_CHECK(c && c->cfm && (c->ready & STTS_W_CFM), "the CfmMelDecoder weights are not finalized (stts_cfm_finalize)");
+  STTS_CHECK(n_utt > 0 && seg_off_host && seg_off_dev && seg_off_host[0] == 0, "bad utterance offsets");
+  STTS_CHECK(curve_off_host && curve_off_dev && curve_off_host[0] == 0, "bad curve offsets");
+  for (int u = 0; u < n_utt; ++u) {
+    STTS_CHECK(seg_off_host[u + 1] > seg_off_host[u], "utterance %d is empty", u);
+    STTS_CHECK(curve_off_host[u + 1] > curve_off_host[u], "utterance %d has an empty F0 / N curve", u);
+  }
+  STTS_CHECK(x && asr && f0 && n_curve && spk_emb && t && sine_noise && out && ws, "null tensor");
+  STTS_HIP(hipSetDevice(c->device));
+  Seg s{n_utt, seg_off_host, seg_off_dev};
+  Arena a(ws, ws_bytes);
+  return cfm_estimator(c, *static_cast<const CfmModel*>(c->cfm.get()), (hipStream_t)stream, s, x, ld_x, asr, ld_asr, f0, n_curve, curve_off_dev, spk_emb, t,
+                       sine_noise, out, ld_out, a);
   API_END
 }
 

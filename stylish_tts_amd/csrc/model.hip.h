@@ -159,6 +159,7 @@ struct stts_ctx {
   std::map<std::string, std::unique_ptr<stts::StyleTable>> op_tables;
   std::map<std::string, std::unique_ptr<stts::MrfW>> op_mrf;
   std::shared_ptr<void> phoneme;  // stts::PhonemeModel (phoneme_model.hip.h)
+  std::shared_ptr<void> cfm;      // stts::CfmModel (cfm.hip.h)
 };
 
 namespace stts {

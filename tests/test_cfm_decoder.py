@@ -47,3 +47,81 @@ def test_inventory_matches_reference_shapes():
     assert "backbone.dec_blocks.3.1.xattn.kv.weight" not in spec and "backbone.enc_blocks.0.0.xattn.q.weight" not in spec
     assert spec["post_tread_trns.blocks.2.attn.rope.freqs"] == (4, 32, 1)
     assert params.count_params(params.cfm_mel_decoder_spec()) == 23634097
+
+
+# ----------------------------------------------------------------------------------------------------------------- HIP path
+def _hip(dims):
+    import torch  # noqa: F401
+
+    from stylish_tts_amd.cfm_decoder import CfmMelDecoder
+
+    m = CfmMelDecoder(feat_dim=dims["feat_dim"], asr_dim=dims["asr_dim"], spk_dim=dims["spk_dim"], hidden_dim=dims["hidden_dim"], emb_dim=dims["emb_dim"],
+                      xut_depth=dims["depth"], xut_enc_blocks=dims["enc_blocks"], xut_dec_blocks=dims["dec_blocks"],
+                      tread_config={"prev_trns_depth": dims["prev_depth"], "post_trns_depth": dims["post_depth"], "dropout_ratio": 0.5})
+    return m.load_state_dict(_weights(dims))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["default", "small"])
+def test_hip_estimator_matches_reference(tag):
+    import torch
+
+    g, dims = load_golden("cfm_decoder"), CASES[tag]
+    m = _hip(dims)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    y = m._forward(d(g[tag + "_x"]), d(g[tag + "_asr"]), d(g[tag + "_f0"]), d(g[tag + "_n"]), d(g[tag + "_spk"]), d(g[tag + "_t"]),
+                   sine_noise=d(g[tag + "_nz"])).cpu().numpy()
+    ref = g[tag + "_y"]
+    assert y.shape == ref.shape and np.isfinite(y).all()
+    # fp32 on both sides; 16 (6) transformer blocks deep, different summation orders
+    assert np.abs(y - ref).max() < 1e-4 * np.abs(ref).max(), np.abs(y - ref).max()
+
+
+@pytest.mark.gpu
+def test_hip_sampling_matches_reference():
+    import torch
+
+    g, dims = load_golden("cfm_decoder"), CASES["small"]
+    m = _hip(dims)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    steps = int(g["sample_steps"])
+    y = m(d(g["small_asr"]), d(g["small_f0"]), d(g["small_n"]), d(g["small_spk"]), steps, float(g["sample_temperature"]), z=d(g["sample_z"]),
+          sine_noise=[d(g[f"sample_nz{i}"]) for i in range(steps)]).cpu().numpy()
+    assert np.abs(y - g["sample_y"]).max() < 1e-4 * np.abs(g["sample_y"]).max()
+
+
+@pytest.mark.gpu
+def test_hip_packed_ragged_batch_is_per_utterance():
+    """Utterances of different lengths in one packed call (the reference needs equal lengths in a batch) = each one alone, and
+    = the oracle; F0 / N curves of another length are resampled per utterance."""
+    import torch
+
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.runtime import Segments
+
+    dims = CASES["small"]
+    m, sd = _hip(dims), _weights(dims)
+    lens, clens = [41, 7, 96], [41, 20, 50]
+    rng = lambda nm, shape: synth.normal("cfmr." + nm, shape)  # noqa: E731
+    xs = [rng(f"x{i}", (1, dims["feat_dim"], n)) for i, n in enumerate(lens)]
+    asrs = [rng(f"a{i}", (1, dims["asr_dim"], n)) for i, n in enumerate(lens)]
+    f0s = [synth.pitch_curve(f"cfmr.f{i}", 1, L) for i, L in enumerate(clens)]
+    ncs = [(synth.uniform(f"cfmr.n{i}", (1, L)) * 2 + 2).astype(np.float32) for i, L in enumerate(clens)]
+    spk = rng("spk", (3, dims["spk_dim"]))
+    t = np.array([0.1, 0.5, 0.9], np.float32)
+    nzs = [rng(f"z{i}", (1, n, 1)) for i, n in enumerate(lens)]
+    dev = m.device
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ld_asr = (dims["asr_dim"] + 31) // 32 * 32
+    xr = d(np.concatenate([x[0].T for x in xs]))
+    ar = torch.zeros(sum(lens), ld_asr, device=dev)
+    ar[:, : dims["asr_dim"]] = d(np.concatenate([a[0].T for a in asrs]))
+    seg, cseg = Segments(lens, dev), Segments(clens, dev)
+    out = m.estimator_packed(seg, xr, ar, d(np.concatenate([f[0] for f in f0s])), d(np.concatenate([c[0] for c in ncs])), cseg, d(spk), d(t),
+                             d(np.concatenate([z.reshape(-1) for z in nzs]))).cpu().numpy()
+    for i, n in enumerate(lens):
+        ref = O.cfm_mel_decoder_forward(xs[i], asrs[i], f0s[i], ncs[i], spk[i : i + 1], t[i : i + 1], nzs[i], sd, dims)[0].T
+        got = out[seg.host[i] : seg.host[i + 1]]
+        assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max(), (i, np.abs(got - ref).max())
+        alone = m._forward(d(xs[i]), d(asrs[i]), d(f0s[i]), d(ncs[i]), d(spk[i : i + 1]), d(t[i : i + 1]), sine_noise=d(nzs[i])).cpu().numpy()[0].T
+        assert np.abs(got - alone).max() < 2e-6 * np.abs(ref).max()
