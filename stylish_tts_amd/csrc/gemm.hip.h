@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
   // two stages of [X rows | W rows] x 32 channels (16-bit operands: half of it; the K-group reduction of KSPLIT = 2 needs the full
   // size); the 16-bit LDS-DMA path keeps three stages so that tiles are requested two iterations ahead
-  constexpr int NSTAGE = (B16 && GLDS) ? 3 : 2;
+  // (three for the 256-row tiles; EIGHT for the 128 x 128 tile of small batches, whose K iteration - four MFMAs per wave - is far
+  //  shorter than a memory round trip: with tiles requested two iterations ahead that loop ran at one iteration per ~0.6 us)
+  constexpr int NSTAGE = (B16 && GLDS) ? ((BM + BN) <= 256 ? 8 : 3) : 2;
   __shared__ f32x4 lds[NSTAGE * (BN + BM) * ((B16 && KSPLIT == 1) ? 4 : 8)];
 
   // XCD-aware block -> tile map (guide T1; speed only, any placement is correct): workgroups are dealt round-robin
@@ -527,29 +529,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
           }
         }
       };
-      auto wait_all_but_newest = [&]() {
-        static_assert(PER >= 1 && PER <= 6, "vmcnt immediate");
-        if constexpr (PER == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if constexpr (PER == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if constexpr (PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // wait until only the NSTAGE - 2 newest tiles' requests of this wave are outstanding: the next tile to multiply has landed
+      constexpr int INFLIGHT = (NSTAGE - 2) * PER;
+      static_assert(INFLIGHT >= 1 && INFLIGHT <= 63, "vmcnt immediate");
+      auto wait_next_tile = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt((INFLIGHT & 15) | (7 << 4) | (15 << 8) | ((INFLIGHT >> 4) << 14));  // vmcnt(INFLIGHT), gfx9 encoding
+        asm volatile("" ::: "memory");
       };
-      issue(0);
-      issue(1);  // (the cursor re-issues the last tile once it runs off the end: harmless, nobody multiplies it)
-      wait_all_but_newest();
+#pragma unroll
+      for (int q = 0; q < NSTAGE - 1; ++q) issue(q);  // (the cursor re-issues the last tile once it runs off the end: harmless, nobody multiplies it)
+      wait_next_tile();
       __syncthreads();
       stamp(1);
-      int cur = 0, nxt = 2;
+      int cur = 0, nxt = NSTAGE - 1;
       for (int it = 0; it < total; ++it) {
-        if (!ablate(8)) issue(nxt);  // tile it+2 -> the stage tile it-1 was read from (every wave has passed the barrier since)
+        if (!ablate(8)) issue(nxt);  // tile it + NSTAGE - 1 -> the stage tile it - 1 was read from (every wave has passed the barrier since)
         mma_step16(cur, 0);
         mma_step16(cur, 1);
-        wait_all_but_newest();       // tile it+1 has landed (this wave's share; the barrier covers the others')
+        wait_next_tile();            // tile it + 1 has landed (this wave's share; the barrier covers the others')
         if (!ablate(2)) __syncthreads();
-        cur = cur == 2 ? 0 : cur + 1;
-        nxt = nxt == 2 ? 0 : nxt + 1;
+        cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+        nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead requests before the stages are reused / the block ends
       __syncthreads();
@@ -1109,12 +1110,16 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     if (npad % 256 == 0 && iters >= 128 && rt256 * (npad / 256) >= 3 * kCUs / 2) tile = 14;
     else if (rt256 * (npad / 128) >= 3 * kCUs / 2) tile = 15;
     if (tile == 14 || tile == 15) plan = Plan();
+    if (const char* e = getenv("STTS_TILE16")) {  // experiment switch: tile for every 16-bit-row store launch
+      tile = atoi(e);
+      plan = Plan();
+    }
   }
   STTS_CHECK(!(a.x16 && (tile == 8 || tile == 11 || tile == 13 || a.xaff)), "conv_gemm: 16-bit activation rows need a plain register-staged tile");
   STTS_CHECK(!((tile == 14 || tile == 15) && (a.prec == PREC_F32 || epi != EPI_STORE)), "conv_gemm: tiles 14 / 15 are for 16-bit operand store launches");
-  STTS_CHECK(!((tile == 16 || tile == 17) && (a.prec == PREC_F32 || epi != EPI_STORE || !a.x16)), "conv_gemm: tiles 16 / 17 are for 16-bit activation rows, store epilogue");
+  STTS_CHECK(!((tile >= 16 && tile <= 18) && (a.prec == PREC_F32 || epi != EPI_STORE || !a.x16)), "conv_gemm: tiles 16 - 18 are for 16-bit activation rows, store epilogue");
   STTS_CHECK((tile != 14 && tile != 16) || npad % 256 == 0, "conv_gemm: tiles 14 / 16 need cout padded to 256");
-  const int bn = (tile >= 14 && tile <= 17) ? 256 : (tile == 5 || tile == 8 || tile == 11) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
+  const int bn = (tile >= 14 && tile <= 17) ? 256 : (tile == 5 || tile == 8 || tile == 11 || tile == 18) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
   if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
   if (tile == 8) {
     plan.full_rt = row_tiles(bn);
@@ -1183,6 +1188,9 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
           break;
         case 17:
           if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+          break;
+        case 18:  // 128 x 128, 8 waves, LDS-DMA with eight stages: one-round launches of small batches in the 16-bit modes
+          if constexpr (PR != PREC_F32) launch_cfg<128, 128, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
           break;
         case 11:
           if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves

@@ -846,7 +846,13 @@ inline dim3 rows_grid(const Seg& s, int per_row_work) {
   return dim3((unsigned)std::min<long>(std::max<long>(1, ceil_div((int)std::min<long>(total, 1 << 30), 256)), 512), s.n_utt);
 }
 
-constexpr long kRows16 = 12288;  // rows from which the 16-bit operand modes keep contraction inputs as 16-bit rows in HBM
+// rows from which the 16-bit operand modes keep contraction inputs as 16-bit rows in HBM (B = 4 x 3 s; measured bf16, 3-s utterances:
+// B = 1: 827 vs 739 utt/s without / with 16-bit rows, B = 2: 1 424 vs 1 313, B = 4: 2 272 vs 2 304, B = 8: 3 442 vs 3 522)
+inline long rows16_threshold() {
+  static const long v = getenv("STTS_ROWS16") ? atol(getenv("STTS_ROWS16")) : 3840;
+  return v;
+}
+#define kRows16 (stts::rows16_threshold())
 
 // AdaIN + activation: Y[:, :ldy] = act((1+gamma) * InstanceNorm(X[:, :C]) + beta), zeros in the pad columns.
 // part: scratch of adain_part_floats(s, C) floats.
@@ -1391,8 +1397,8 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   const int ldl = logamp_out ? ld_lp : ldlp;
   // 16-bit operand modes: every contraction input of the body is a 16-bit row buffer written by its producer (LayerNorm
   // outputs, the SiLU output of pwconv1, the head inputs) - nrm / U / headA / headP are reinterpreted; mel gets a rounded copy
-  // (from kRows16 rows on: below that the contractions are latency-bound one-round launches and the extra copies cost more
-  //  than the staging they save - B = 8 x 3 s: 3 520 vs 3 360 utt/s)
+  // (from rows16_threshold() rows on: below that the contractions are latency-bound one-round launches and the extra copies cost more
+  //  than the staging they save)
   const int p16 = (c->prec != PREC_F32 && vocoder_rows16(c, R)) ? c->prec : 0;
   unsigned short* mel16 = (p16 && !mel16_in) ? ws.get<unsigned short>(R * round_up(d.gen_input, 32)) : nullptr;
   float* yw = ws.get<float>((R + s.n_utt) * kWin);

@@ -73,6 +73,11 @@ def rounded_oracle():
         (578, 512, 3, 1, [260, 255, 257, 31], 117),
         (1024, 256, 7, 1, [513], 117),
         (64, 130, 7, 3, [77, 5], 117),
+        # ... and the 128-row LDS-DMA tile with eight stages (more stages than K iterations, exactly as many, and many more iterations)
+        (96, 256, 1, 1, [130, 5], 118),
+        (256, 128, 1, 1, [128], 118),
+        (578, 512, 3, 1, [200, 37, 129], 118),
+        (768, 1024, 7, 1, [300, 17], 118),
     ],
 )
 def test_conv1d_16bit_matches_rounded_oracle(hip32, rounded_oracle, prec, cin, cout, k, dil, lengths, tile):
