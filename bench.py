@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--mel-frames", type=int, default=240, help="mel frames per utterance (cfg2 = 240 = 3.0 s)")
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
                     help="operand precision of the contractions; f32 = BASELINE cfg2 (the bench line), bf16 / f16 = cfg3 / cfg5 arithmetic (side experiments)")
-    ap.add_argument("--cpu-utts", type=int, default=4, help="utterances the CPU baseline times (bounded sample)")
+    ap.add_argument("--cpu-utts", type=int, default=16, help="utterances the CPU baseline times (bounded sample: ~10-20 s of host work)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the counter passes run this script with the legs off
     ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
@@ -422,13 +422,15 @@ def main():
             from oracle import stylish_oracle as O
 
             h = inp["host"]
-            n_utts = max(1, args.cpu_utts)
+            per_call = min(BATCH, max(1, args.cpu_utts))  # the workload's own batch per oracle call: BLAS sees the same matrix shapes the GPU step does
+            calls = max(1, args.cpu_utts // per_call)
+            n_utts = calls * per_call
+            asr_b = np.ascontiguousarray(h["asr"][: per_call * T4].reshape(per_call, T4, -1).transpose(0, 2, 1))
+            pitch_b, energy_b = h["pitch"][: per_call * T4].reshape(per_call, T4), h["energy"][: per_call * T4].reshape(per_call, T4)
+            nzb = dict(prior_noise=h["nz"]["prior_noise"][:per_call], src_noise=h["nz"]["src_noise"][:per_call], init_phase=h["nz"]["init_phase"])
             t1 = time.perf_counter()
-            for b in range(n_utts):
-                bb = b % BATCH
-                sl = slice(bb * T4, (bb + 1) * T4)
-                nzb = dict(prior_noise=h["nz"]["prior_noise"][bb : bb + 1], src_noise=h["nz"]["src_noise"][bb : bb + 1], init_phase=h["nz"]["init_phase"])
-                O.frame_path(h["asr"][sl].T[None].copy(), h["pitch"][sl][None], h["energy"][sl][None], h["style"][bb : bb + 1], nzb, sd)
+            for _ in range(calls):
+                O.frame_path(asr_b, pitch_b, energy_b, h["style"][:per_call], nzb, sd)
             cpu_t = time.perf_counter() - t1
             try:  # the threads the oracle's matrix products actually ran on
                 from threadpoolctl import threadpool_info
@@ -441,7 +443,7 @@ def main():
                 "unit": "utt/s",
                 "cores": blas_threads,
                 "kind": "port",
-                "sample": f"{n_utts} utterances of the same workload (3.0 s each, B=1 per call), numpy oracle; BLAS pool = {blas_threads} threads "
+                "sample": f"{n_utts} utterances of the same workload (3.0 s each, {per_call} per oracle call like the GPU step, {calls} calls), numpy oracle; BLAS pool = {blas_threads} threads "
                           f"of {os.cpu_count()} logical cores",
                 "reference_torch_cpu_note": "survey container, 8 vCPU, reference torch-CPU code: 1.4 utt/s at B=1, 1.9-2.5 utt/s at B=8 (BASELINE.md §2)",
             }
