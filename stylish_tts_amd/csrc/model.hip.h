@@ -78,7 +78,7 @@ struct AdainBlockW {
 
 // fragment-order weights of one coupling layer for wn_fused_kernel (fp32 mode; wn_fused.hip.h)
 struct WnFusedW {
-  float* W1[2][4] = {};  // [0: F(2,5), 1: F(4,5)][WaveNet layer]: transformed in_layers planes
+  float* W1[3][4] = {};  // [0: F(2,5), 1: F(4,5), 2: direct (M = 1)][WaveNet layer]: transformed in_layers planes
   float* b1[4] = {};     // in_layers bias, natural order [256]
   float* W2[4] = {};     // res_skip_layers
   float* b2[4] = {};
@@ -428,9 +428,10 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
       }, f32_to_bf16, f32_to_f16);
       STTS_TRY(dev_upload(c, f16v, &o->H1[i]));
     }
-    for (int v = 0; v < 2 && c->prec == PREC_F32; ++v) {
+    for (int v = 0; v < 3 && c->prec == PREC_F32; ++v) {
       WnFusedMats mt;
-      STTS_CHECK(wn_fused_matrices(v == 0 ? 2 : 4, &mt), "wn_fused: F(%d,5) matrices failed their self-check", v == 0 ? 2 : 4);
+      const int vm = v == 0 ? 2 : (v == 1 ? 4 : 1);
+      STTS_CHECK(wn_fused_matrices(vm, &mt), "wn_fused: F(%d,5) matrices failed their self-check", vm);
       const int nc = mt.n;
       std::vector<std::vector<double>> plane((size_t)nc * 2 * C, std::vector<double>(C));  // [component][output row][cin]
       for (int j = 0; j < nc; ++j)
@@ -1143,10 +1144,19 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       const int force = getenv("STTS_WN_M") ? atoi(getenv("STTS_WN_M")) : 0;  // tests / tools: force a block shape
       constexpr int kT16 = 22, kT2 = 28, kT4 = 41;
       const int t16 = ceil_div((int)b16, 256) * kT16, t2 = ceil_div((int)b32, 256) * kT2, t4 = ceil_div((int)b64, 256) * kT4;
+      // the same kernel in its direct form on 16-row blocks (M = 1) takes the place of the staged 16-row kernel for the smallest
+      // batches (B = 1: 19.9 vs 21.1 us per layer, B = 4: 22.0 vs 23.2; F(2,5) there: 25.3 / 27.4)
+      constexpr int kT1 = 21;
+      const int t1 = ceil_div((int)b16, 256) * kT1;
+      (void)t16;
       fused_m = t4 < t2 ? 4 : 2;
-      if (t16 <= std::min(t2, t4)) fused_m = 0;
-      rows16 = fused_m == 0;
-      if (force == 2 || force == 4) fused_m = force;
+      if (t1 <= std::min(t2, t4)) fused_m = 1;
+      rows16 = false;
+      if (force == 1 || force == 2 || force == 4) fused_m = force;
+      if (force == 16) {  // the staged 16-row kernel (kept for comparison)
+        fused_m = 0;
+        rows16 = true;
+      }
     }
   }
   // 16-bit operand modes: wn_fused16_kernel on 64- or 128-row blocks (the taller block halves the weight stream per row; it
@@ -1236,7 +1246,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
           WnFusedArgs<M> fa;
           memset(&fa, 0, sizeof(fa));
           fa.Hin = hcur; fa.Hout = w.Hout; fa.Out = outf; fa.seg_off = s.dev;
-          fa.W1 = L.fused.W1[M == 2 ? 0 : 1][i]; fa.b1 = L.fused.b1[i]; fa.W2 = L.fused.W2[i]; fa.b2 = L.fused.b2[i];
+          fa.W1 = L.fused.W1[M == 2 ? 0 : (M == 4 ? 1 : 2)][i]; fa.b1 = L.fused.b1[i]; fa.W2 = L.fused.W2[i]; fa.b2 = L.fused.b2[i];
           fa.gate = cond; fa.ld_gate = w.ld_gate; fa.gcol0 = w.gcol0; fa.out_acc = w.out_acc; fa.tail = w.tail;
           fa.W3 = L.fused.W3; fa.b3m = L.fused.b3m; fa.b3s = L.fused.b3s; fa.Z = w.Z; fa.ldz = w.ldz; fa.zcol0 = w.zcol0;
           if (w.tail > 1) { fa.W4 = c->flow[f - 1].fused.W4; fa.b4 = c->flow[f - 1].fused.b4; fa.Hpre = w.Hpre; }
@@ -1251,7 +1261,8 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
           if (i == 3) STTS_LAUNCH_TIMED((wn_fused_kernel<M, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, fa);
           else STTS_LAUNCH_TIMED((wn_fused_kernel<M, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, fa);
         };
-        if (fused_m == 4) launch(std::integral_constant<int, 4>{});
+        if (fused_m == 1) launch(std::integral_constant<int, 1>{});
+        else if (fused_m == 4) launch(std::integral_constant<int, 4>{});
         else launch(std::integral_constant<int, 2>{});
       }
       else if (fused16_rt) {

@@ -48,6 +48,11 @@ constexpr int kWnWaves = 4;  // waves per block: one per SIMD (two per SIMD ran 
 template <int M>
 struct WnConst;
 template <>
+struct WnConst<1> {  // "F(1,5)": the direct form - component j is the input row at offset j - 2, its plane is tap j (16-row blocks for the smallest batches)
+  static constexpr double Bt[5][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 0, 0}, {0, 0, 1, 0, 0}, {0, 0, 0, 1, 0}, {0, 0, 0, 0, 1}};
+  static constexpr double At[1][5] = {{1, 1, 1, 1, 1}};
+};
+template <>
 struct WnConst<2> {
   static constexpr double Bt[6][6] = {{1.0, 1.5, -2.0, -1.5, 1.0, 0.0},
                                       {0.0, 1.0 / 3.0, 5.0 / 6.0, 1.0 / 6.0, -1.0 / 3.0, 0.0},
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(256) wn_fused_kernel(const WnFusedArgs<M> a) {
   // step ahead of the MFMAs that consume it, one load between every four MFMAs.  A ring step covers CPB components of one
   // 16-channel block: all 6 for F(2,5) (24 KB per wave), 4 of the 8 for F(4,5) (16 KB; its 128 accumulator registers leave
   // no room for two whole blocks).
-  constexpr int CPB = M == 2 ? NC : NC / 2, SPB = NC / CPB, NS1 = KB * SPB;  // components per step, steps per block, steps
+  constexpr int CPB = M <= 2 ? NC : NC / 2, SPB = NC / CPB, NS1 = KB * SPB;  // components per step, steps per block, steps
   constexpr int T1 = CPB * 2 * CT;                                            // fragments (1 KB each) per wave and step
   const f32x4* w1 = reinterpret_cast<const f32x4*>(a.W1) + (size_t)w * NS1 * (T1 * 64) + lane;
   f32x4 bq0[T1], bq1[T1];
@@ -442,6 +447,17 @@ struct WnFusedMats {
 };
 inline bool wn_fused_matrices(int m, WnFusedMats* out) {
   const int r = 5, n = m + r - 1;
+  if (m == 1) {  // the direct form: identity transforms
+    *out = WnFusedMats();
+    out->m = 1;
+    out->n = 5;
+    for (int j = 0; j < 8; ++j) {
+      for (int qq = 0; qq < 8; ++qq) out->Bt[j][qq] = (j < 5 && j == qq) ? 1.0 : 0.0;
+      for (int k = 0; k < 5; ++k) out->G[j][k] = (j < 5 && j == k) ? 1.0 : 0.0;
+      for (int i = 0; i < 4; ++i) out->At[i][j] = (i == 0 && j < 5) ? 1.0 : 0.0;
+    }
+    return true;
+  }
   if (m != 2 && m != 4) return false;
   const double all[7] = {0, 1, -1, 2, -0.5, -2, 0.5};
   std::vector<double> pts(all, all + (n - 1));

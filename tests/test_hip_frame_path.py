@@ -134,9 +134,10 @@ def test_prior_flow_golden(hip):
     close(cm(mel, 1, 512, 64), g["mel"], what="post_flow")
 
 
-@pytest.mark.parametrize("m", ["2", "4"])
+@pytest.mark.parametrize("m", ["1", "2", "4", "16"])
 def test_prior_flow_fused_wavenet_kernel(hip, weights, m, monkeypatch):
-    """wn_fused_kernel (F(2,5) with 32-row blocks / F(4,5) with 64-row blocks; picked by batch size in production) forced
+    """wn_fused_kernel (direct form with 16-row blocks / F(2,5) with 32-row blocks / F(4,5) with 64-row blocks; picked by batch
+    size in production; "16" = the staged 16-row kernel it replaced for the smallest batches) forced
     on small and ragged inputs: the reference golden, and per-utterance oracle runs for lengths that leave partial
     blocks, one-row tails and utterances shorter than the conv's reach."""
     from oracle import stylish_oracle as O
