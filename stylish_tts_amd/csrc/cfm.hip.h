@@ -186,6 +186,15 @@ __global__ void __launch_bounds__(256) gated_residual_kernel(const float* __rest
   }
 }
 
+// in place: X = mish(X) over a dense [rows, C] buffer
+__global__ void __launch_bounds__(256) mish_kernel(float* __restrict__ X, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = reinterpret_cast<float4*>(X)[i];
+    v.x = mishf(v.x); v.y = mishf(v.y); v.z = mishf(v.z); v.w = mishf(v.w);
+    reinterpret_cast<float4*>(X)[i] = v;
+  }
+}
+
 // SwiGLU gate (xut/layers.py:23-29): U = silu(A[:, :M]) * A[:, M:]
 __global__ void __launch_bounds__(256) swiglu_kernel(const float* __restrict__ A, int M, float* __restrict__ U, long rows) {
   const int nv = M / 4;
@@ -333,7 +342,8 @@ inline int cfm_estimator(stts_ctx* c, const CfmModel& M, hipStream_t st, const S
   STTS_CHECK(ld_x >= d.feat && ld_asr % 32 == 0 && ld_asr >= d.asr && ld_out >= d.feat, "cfm_estimator: leading dimensions too small (asr rows must be padded to 32 columns)");
   STTS_CHECK(s.max_len() <= kAttnMaxKeys, "cfm_estimator: utterances of more than %d frames are not supported (%d)", kAttnMaxKeys, s.max_len());
   // conditioning that does not depend on x
-  STTS_TRY(cfm_linear(st, s, asr, ld_asr, M.asr1, ACT_MISH, a1, 4 * d.emb));
+  STTS_TRY(cfm_linear(st, s, asr, ld_asr, M.asr1, ACT_NONE, a1, 4 * d.emb));
+  hipLaunchKernelGGL(mish_kernel, dim3((unsigned)std::min<long>(2048, ceil_div(R * d.emb, 256L))), dim3(256), 0, st, a1, R * d.emb);  // R * 4 emb / 4 float4s
   STTS_TRY(cfm_linear(st, s, a1, 4 * d.emb, M.asr3, ACT_NONE, ae, d.emb));
   STTS_TRY(run_small(st, M.spk0, spk, d.spk, 1, s1, 4 * d.emb, U));
   STTS_TRY(run_small(st, M.spk2, s1, 4 * d.emb, 0, se, d.emb, U));

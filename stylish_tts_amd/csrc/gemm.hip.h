@@ -35,7 +35,7 @@ namespace stts {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;  // native vector: stays in VGPRs (HIP's float4 struct copies via memcpy)
 
-enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_LRELU = 4, ACT_MISH = 5 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_LRELU = 4 };
 enum Epi {
   EPI_STORE = 0,      // Y = (act(acc + bias) [+ R]) * alpha ; optional per-tile sum of squares
   EPI_GATE = 1,       // paired: Y = tanh(a + g[utt][c]) * sigmoid(b + g[utt][C + c])      (flow.py:7-14)
@@ -116,7 +116,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     case ACT_RELU: return fmaxf(v, 0.0f);
     case ACT_LRELU: return v >= 0.0f ? v : 0.2f * v;
-    case ACT_MISH: return v * tanhf(v > 20.0f ? v : log1pf(expf(v)));  // x tanh(softplus(x)), torch's softplus threshold
+    // (keep this switch small: it is inlined per element into every contraction epilogue and into the LayerNorm kernel - a Mish case
+    //  here (tanh, log1p, exp) cost the bf16 B = 64 frame path 7 %; cfm.hip.h applies Mish in its own pass)
     default: return v;
   }
 }
