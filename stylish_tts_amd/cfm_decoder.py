@@ -34,6 +34,15 @@ class CfmMelDecoder:
         self._ws: Optional[torch.Tensor] = None
         self._ready = False
 
+    @classmethod
+    def from_model_config(cls, cfg=None, **kw):
+        """The instance build_model makes (models/models.py:65-70): feat_dim = n_mels, asr_dim = hubert.hidden_dim,
+        spk_dim = speaker_embedder.hidden_dim, hidden_dim = decoder.hidden_dim; everything else at the class defaults."""
+        from .config import load_model_config
+
+        cfg = cfg if cfg is not None else load_model_config()
+        return cls(feat_dim=cfg.n_mels, asr_dim=cfg.hubert.hidden_dim, spk_dim=cfg.speaker_embedder.hidden_dim, hidden_dim=cfg.decoder.hidden_dim, **kw)
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Mapping[str, "np.ndarray | torch.Tensor"]):
         self.model.load_state_dict("cfm_mel_decoder", sd)

@@ -88,6 +88,9 @@ DEFAULT_MODEL = {
         "last_dropout": 0.5,
     },
     "pitch_energy_predictor": {"inter_dim": 256, "dropout": 0.2},
+    # feature extractors whose OUTPUT WIDTHS size the flow-matching mel decoder (model.yml:68-74; the extractors themselves are given tensors)
+    "hubert": {"hidden_dim": 768},
+    "speaker_embedder": {"hidden_dim": 10240},
     # text symbols (model.yml:81-85); index = position in pad + punctuation + letters + letters_ipa
     "symbol": {
         "pad": '$',

@@ -125,3 +125,27 @@ def test_hip_packed_ragged_batch_is_per_utterance():
         assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max(), (i, np.abs(got - ref).max())
         alone = m._forward(d(xs[i]), d(asrs[i]), d(f0s[i]), d(ncs[i]), d(spk[i : i + 1]), d(t[i : i + 1]), sine_noise=d(nzs[i])).cpu().numpy()[0].T
         assert np.abs(got - alone).max() < 2e-6 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_hip_estimator_at_the_model_config_size():
+    """The instance the reference's build_model constructs (models/models.py:65-70 with the default model.yml): hidden 512 (8 heads of
+    64), HuBERT width 768, speaker-embedding width 10 240.  No reference vector at this size: against the oracle pinned above."""
+    import torch
+
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.cfm_decoder import CfmMelDecoder
+
+    m = CfmMelDecoder.from_model_config()
+    dims = dict(params.CFM_DEFAULT_DIMS, feat_dim=80, asr_dim=768, spk_dim=10240, hidden_dim=512)
+    assert (m.dims.hidden_dim, m.dims.asr_dim, m.dims.spk_dim, m.dims.feat_dim) == (512, 768, 10240, 80)
+    sd = _weights(dims)
+    m.load_state_dict(sd)
+    B, n, L = 2, 45, 31
+    x, asr = synth.normal("cfmp.x", (B, 80, n)), synth.normal("cfmp.a", (B, 768, n))
+    f0, nc = synth.pitch_curve("cfmp.f", B, L), (synth.uniform("cfmp.n", (B, L)) * 2 + 2).astype(np.float32)
+    spk, t, nz = synth.normal("cfmp.s", (B, 10240)), np.array([0.2, 0.7], np.float32), synth.normal("cfmp.z", (B, n, 1))
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    y = m._forward(d(x), d(asr), d(f0), d(nc), d(spk), d(t), sine_noise=d(nz)).cpu().numpy()
+    ref = O.cfm_mel_decoder_forward(x, asr, f0, nc, spk, t, nz, sd, dims)
+    assert np.abs(y - ref).max() < 1e-4 * np.abs(ref).max(), np.abs(y - ref).max()
