@@ -59,52 +59,81 @@ __global__ void __launch_bounds__(256) rope_kernel(float* __restrict__ X, int ld
 // band (cross-attention of the pitch/energy predictor): the reference builds "True = NOT allowed" but the attention fills
 // -1e4 where its mask is FALSE (pitch_energy_predictor.py:194-212 vs text_encoder.py:255-262), so scores are lowered by
 // 1e4 INSIDE |key - centre[query]| <= window and untouched outside.  Reproduced as is.
-constexpr int kAttnMaxKeys = 1024, kAttnMaxKc = 192;
+constexpr int kAttnMaxKeys = 1024, kAttnMaxKc = 192, kAttnQ = 4;
+// A wave owns kAttnQ consecutive queries of one head: a key row (phase 1) or a value element (phase 2) is fetched once and used
+// for all of them - a quarter of the K / V traffic of one query per wave, which is what bound this kernel on the 240-800-frame
+// sequences of the flow-matching decoder.  Per query the arithmetic and its order are unchanged.
 __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
                                                         int kcol0, const float* __restrict__ V, int ldv, int vcol0, float* __restrict__ O, int ldo,
                                                         int n_heads, int kc, const int* __restrict__ q_off, const int* __restrict__ k_off,
                                                         const int* __restrict__ band_centre, int window, float scale) {
-  __shared__ float sq[4][kAttnMaxKc];
-  __shared__ float sp[4][kAttnMaxKeys];
+  __shared__ float sq[4][kAttnQ][kAttnMaxKc];
+  __shared__ float sp[4][kAttnQ][kAttnMaxKeys];
   const int u = blockIdx.z, h = blockIdx.y;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qlo = q_off[u], nq = q_off[u + 1] - qlo;
   const int klo = k_off[u], nk = k_off[u + 1] - klo;
-  const int qi = blockIdx.x * 4 + w;
-  if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
-  const float* q = Q + (long)(qlo + qi) * ldq + qcol0 + h * kc;
-  for (int c = lane; c < kc; c += 64) sq[w][c] = q[c];
+  const int q0 = (blockIdx.x * 4 + w) * kAttnQ;
+  if (q0 >= nq) return;  // whole wave exits together; no block-level barrier is used below
+  const int nqw = min(kAttnQ, nq - q0);
+  int centre[kAttnQ];
+#pragma unroll
+  for (int qq = 0; qq < kAttnQ; ++qq) {
+    const int qi = q0 + min(qq, nqw - 1);  // (a short last group repeats its last query: computed, not stored)
+    const float* q = Q + (long)(qlo + qi) * ldq + qcol0 + h * kc;
+    for (int c = lane; c < kc; c += 64) sq[w][qq][c] = q[c];
+    centre[qq] = band_centre ? band_centre[qlo + qi] : 0;
+  }
   __builtin_amdgcn_wave_barrier();
-  const int centre = band_centre ? band_centre[qlo + qi] : 0;
-  float mx = -INFINITY;
+  float mx[kAttnQ];
+#pragma unroll
+  for (int qq = 0; qq < kAttnQ; ++qq) mx[qq] = -INFINITY;
   for (int j = lane; j < nk; j += 64) {
     const float* kr = K + (long)(klo + j) * ldk + kcol0 + h * kc;
-    float s = 0.f;
+    float s[kAttnQ];
+#pragma unroll
+    for (int qq = 0; qq < kAttnQ; ++qq) s[qq] = 0.f;
     for (int c = 0; c < kc; c += 4) {
       const float4 kv = *reinterpret_cast<const float4*>(kr + c);
-      s += sq[w][c] * kv.x + sq[w][c + 1] * kv.y + sq[w][c + 2] * kv.z + sq[w][c + 3] * kv.w;
-    }
-    s *= scale;
-    if (band_centre && j >= centre - window && j <= centre + window) s += -1e4f;
-    sp[w][j] = s;
-    mx = fmaxf(mx, s);
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  float sum = 0.f;
-  for (int j = lane; j < nk; j += 64) {
-    const float e = expf(sp[w][j] - mx);
-    sp[w][j] = e;
-    sum += e;
+      for (int qq = 0; qq < kAttnQ; ++qq) s[qq] += sq[w][qq][c] * kv.x + sq[w][qq][c + 1] * kv.y + sq[w][qq][c + 2] * kv.z + sq[w][qq][c + 3] * kv.w;
+    }
+#pragma unroll
+    for (int qq = 0; qq < kAttnQ; ++qq) {
+      float v = s[qq] * scale;
+      if (band_centre && j >= centre[qq] - window && j <= centre[qq] + window) v += -1e4f;
+      sp[w][qq][j] = v;
+      mx[qq] = fmaxf(mx[qq], v);
+    }
   }
-  sum = wave_sum(sum);
+  float inv[kAttnQ];
+#pragma unroll
+  for (int qq = 0; qq < kAttnQ; ++qq) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx[qq] = fmaxf(mx[qq], __shfl_xor(mx[qq], o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) {
+      const float e = expf(sp[w][qq][j] - mx[qq]);
+      sp[w][qq][j] = e;
+      sum += e;
+    }
+    inv[qq] = 1.0f / wave_sum(sum);
+  }
   __builtin_amdgcn_wave_barrier();
-  const float inv = 1.0f / sum;
-  float* o = O + (long)(qlo + qi) * ldo + h * kc;
   for (int c = lane; c < kc; c += 64) {
-    float acc = 0.f;
-    for (int j = 0; j < nk; ++j) acc += sp[w][j] * V[(long)(klo + j) * ldv + vcol0 + h * kc + c];
-    o[c] = acc * inv;
+    const float* vp = V + (long)klo * ldv + vcol0 + h * kc + c;
+    float acc[kAttnQ];
+#pragma unroll
+    for (int qq = 0; qq < kAttnQ; ++qq) acc[qq] = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < nk; ++j) {
+      const float v = vp[(long)j * ldv];
+#pragma unroll
+      for (int qq = 0; qq < kAttnQ; ++qq) acc[qq] += sp[w][qq][j] * v;
+    }
+#pragma unroll
+    for (int qq = 0; qq < kAttnQ; ++qq)
+      if (qq < nqw) O[(long)(qlo + q0 + qq) * ldo + h * kc + c] = acc[qq] * inv[qq];
   }
 }
 

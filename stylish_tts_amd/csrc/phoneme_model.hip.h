@@ -282,7 +282,7 @@ inline int run_attention(hipStream_t st, const Seg& sq, const Seg& sk, const flo
                          const float* V, int ldv, int vcol0, float* O, int ldo, int heads, int kc, const int* band_centre, int window) {
   STTS_CHECK(kc <= kAttnMaxKc && kc % 4 == 0, "attention: head size %d unsupported", kc);
   STTS_CHECK(sk.max_len() <= kAttnMaxKeys, "attention: more than %d keys (%d)", kAttnMaxKeys, sk.max_len());
-  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(sq.max_len(), 4), heads, sq.n_utt), dim3(256), 0, st, Q, ldq, qcol0, K, ldk, kcol0, V, ldv, vcol0,
+  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(sq.max_len(), 4 * kAttnQ), heads, sq.n_utt), dim3(256), 0, st, Q, ldq, qcol0, K, ldk, kcol0, V, ldv, vcol0,
                      O, ldo, heads, kc, sq.dev, sk.dev, band_centre, window, 1.0f / sqrtf((float)kc));
   STTS_HIP(hipGetLastError());
   return 0;
