@@ -25,12 +25,48 @@ class Synthesizer:
         self.eng = engine
         self.cfg = engine.cfg
         self.text_cleaner = TextCleaner(self.cfg.symbol) if "symbol" in self.cfg else None
+        self._lane = self._new_lane()
+        self._lanes: List[dict] = []  # extra lanes of map(): one per concurrent call
+
+    def _new_lane(self, own_stream: bool = False) -> dict:
         # the three text encoders only share the tokens: two of them (with their style encoders) run on side streams
-        # next to the duration predictor and the host read of the frame counts
-        self._side = [torch.cuda.Stream(device=engine.device) for _ in range(2)]
-        # ... each issued from its own host thread: a text encoder is ~120 launches (~0.5 ms of host time), so one
-        # thread cannot feed three streams (the C calls release the GIL)
-        self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="stts-side")
+        # next to the duration predictor and the host read of the frame counts, each issued from its own host thread: a
+        # text encoder is ~120 launches (~0.5 ms of host time), so one thread cannot feed three streams (the C calls
+        # release the GIL)
+        dev = self.eng.device
+        return dict(side=[torch.cuda.Stream(device=dev) for _ in range(2)], pool=ThreadPoolExecutor(max_workers=2, thread_name_prefix="stts-side"),
+                    main=torch.cuda.Stream(device=dev) if own_stream else None)
+
+    def map(self, batches: Sequence[Sequence[Sequence[int]]], workers: int = 2, noise: Optional[Sequence[Optional[Dict[str, torch.Tensor]]]] = None):
+        """Several batches, `workers` of them in flight: each call runs on its own stream from its own host thread, so one
+        batch's phoneme-rate stages (hundreds of small launches, the host read of its frame counts) overlap another's frame
+        path.  Results in input order; per batch the arithmetic is that of __call__."""
+        if workers <= 1 or len(batches) <= 1:
+            return [self(b, noise=None if noise is None else noise[i]) for i, b in enumerate(batches)]
+        while len(self._lanes) < workers:
+            self._lanes.append(self._new_lane(own_stream=True))
+        caller = torch.cuda.current_stream(self.eng.device)
+        fork = torch.cuda.Event()
+        fork.record(caller)
+
+        def run(i):
+            lane = self._lanes[i % workers]
+            torch.cuda.set_device(self.eng.device)
+            with torch.cuda.stream(lane["main"]):
+                lane["main"].wait_event(fork)
+                out = self._run(batches[i], None if noise is None else noise[i], False, lane)
+                for w in out:
+                    w.record_stream(caller)
+            return out
+
+        if not hasattr(self, "_map_pool") or self._map_pool._max_workers < workers:
+            self._map_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="stts-lane")
+        # a lane serves its batches in order (its stream and workspace are its own), different lanes run concurrently
+        futs = [self._map_pool.submit(lambda k=k: [run(i) for i in range(k, len(batches), workers)]) for k in range(workers)]
+        per_lane = [f.result() for f in futs]
+        for lane in self._lanes[:workers]:
+            caller.wait_stream(lane["main"])
+        return [per_lane[i % workers][i // workers] for i in range(len(batches))]
 
     def infer(self, texts: Sequence[str], noise: Optional[Dict[str, torch.Tensor]] = None, out_prefix: Optional[str] = None, combine: bool = False):
         """Phoneme strings → int16 waveforms, all utterances in one pass (the loop body of ``train/test_onnx.py:48-90``).
@@ -49,8 +85,11 @@ class Synthesizer:
                     write_wav(f"{out_prefix}_{i}.wav", smp, self.cfg.sample_rate)
         return samples
 
-    @torch.no_grad()
     def __call__(self, token_lists: Sequence[Sequence[int]], noise: Optional[Dict[str, torch.Tensor]] = None, return_details: bool = False):
+        return self._run(token_lists, noise, return_details, self._lane)
+
+    @torch.no_grad()
+    def _run(self, token_lists, noise, return_details, lane):
         eng, dev = self.eng, self.eng.device
         L = [len(t) for t in token_lists]
         toks = torch.tensor([int(v) for t in token_lists for v in t], dtype=torch.int64, device=dev)
@@ -69,7 +108,7 @@ class Synthesizer:
                     t.record_stream(main)  # consumed on the caller's stream below
             return e, y
 
-        jobs = [self._pool.submit(encode, 2, self._side[0]), self._pool.submit(encode, 1, self._side[1])]
+        jobs = [lane["pool"].submit(encode, 2, lane["side"][0]), lane["pool"].submit(encode, 1, lane["side"][1])]
         # 1. durations (DurationPredictor + DurationProcessor.prediction_to_duration)
         _, dur = eng.duration(sp, toks)
         csum = torch.cumsum(dur, 0)
@@ -79,8 +118,8 @@ class Synthesizer:
         st = Segments(T, dev)
         st4 = st.scaled(4)
         (pe_enc, pe_style), (enc, style) = jobs[0].result(), jobs[1].result()
-        main.wait_stream(self._side[0])
-        main.wait_stream(self._side[1])
+        main.wait_stream(lane["side"][0])
+        main.wait_stream(lane["side"][1])
         # 2b. pitch / energy (PitchEnergyPredictor on the pe encoders' outputs)
         f0, en = eng.pitch_energy(sp, st, dur, pe_enc, pe_style)
         # 3b. speech predictor front (length regulator, x4 upsampling)

@@ -163,6 +163,33 @@ def test_export_model_end_to_end(mods):
     close(a2.reshape(-1), g["audio"], atol=1e-3, what="export waveform (teacher-forced pitch)")
 
 
+def test_synthesizer_map_equals_sequential_calls(mods, weights, cfg):
+    """Synthesizer.map: batches in flight on their own streams / host threads give exactly what one call after the other gives."""
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.pipeline import Synthesizer
+
+    eng = mods["speech_predictor"].engine
+    for m in mods.values():
+        m.engine
+    syn = Synthesizer(eng)
+    batches = [[synth.tokens(f"map.{j}.{i}", 1, 6 + 3 * ((i + j) % 4), 178)[0].tolist() for i in range(1 + j % 3)] for j in range(7)]
+    noises = []
+    for j, b in enumerate(batches):
+        _, det = syn(b, return_details=True)
+        R4 = 4 * sum(det["frames"])
+        noises.append(dict(prior_noise=dev(synth.normal(f"map.pn{j}", (R4, 128))), src_noise=dev(synth.normal(f"map.sn{j}", (R4 * 75,))),
+                           init_phase=dev(synth.uniform(f"map.ph{j}", (1,)))))
+    seq = [syn(b, noise=nz) for b, nz in zip(batches, noises)]
+    for workers in (2, 3):
+        par = syn.map(batches, workers=workers, noise=noises)
+        torch.cuda.synchronize()
+        assert len(par) == len(seq)
+        for a, b in zip(seq, par):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert x.shape == y.shape and torch.equal(x, y)
+
+
 def test_synthesizer_matches_the_module_composition(mods, weights, cfg):
     """pipeline.Synthesizer (packed ragged batch, one pass) == DurationPredictor -> DurationProcessor -> ExportModel per
     utterance with the same noise (same kernels, utterances are independent)."""

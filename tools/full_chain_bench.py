@@ -18,3 +18,14 @@ for B, P in ((1, 14), (8, 14), (64, 14), (8, 50)):
     for _ in range(n): syn(toks)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"B={B:3d} P={P:3d}: {dt*1e3:8.2f} ms/call  {B/dt:8.1f} utt/s  audio {secs:7.1f} s/call  {secs/dt:8.0f}x real time", flush=True)
+
+# several batches in flight (Synthesizer.map): the phoneme-rate stages and the host read of one batch overlap another's frame path
+for B, P in ((1, 14), (8, 14), (8, 50)):
+    batches = [[synth.tokens(f"fm.{B}.{j}.{i}", 1, P, 178)[0].tolist() for i in range(B)] for j in range(12)]
+    for workers in (1, 2, 3):
+        syn.map(batches[:workers * 2], workers=workers)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = syn.map(batches, workers=workers)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / len(batches)
+        secs = sum(w_.numel() for o in out for w_ in o) / 24000 / len(batches)
+        print(f"map B={B:3d} P={P:3d} workers={workers}: {dt*1e3:8.2f} ms/batch  {B/dt:8.1f} utt/s  {secs/dt:8.0f}x real time", flush=True)
