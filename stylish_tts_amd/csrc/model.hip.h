@@ -853,7 +853,6 @@ inline long rows16_threshold() {
   static const long v = getenv("STTS_ROWS16") ? atol(getenv("STTS_ROWS16")) : 3840;
   return v;
 }
-#define kRows16 (stts::rows16_threshold())
 
 // AdaIN + activation: Y[:, :ldy] = act((1+gamma) * InstanceNorm(X[:, :C]) + beta), zeros in the pad columns.
 // part: scratch of adain_part_floats(s, C) floats.
@@ -904,7 +903,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   const bool wino2 = !fold && wino && *wino && B.w2.ready && !B.sc.W && force_tile == 0;
   // 16-bit operand modes, large batches: the normalised activations are WRITTEN as 16-bit rows (act1 / act2 reinterpreted),
   // so the contractions stage half the bytes and convert nothing; a learned shortcut reads a rounded copy of x (xs16)
-  const int h16 = (s.rows() >= kRows16 && B.conv1.prec != PREC_F32 && force_tile == 0 && (!B.sc.W || xs16) && ldx % 8 == 0) ? B.conv1.prec : 0;
+  const int h16 = (s.rows() >= rows16_threshold() && B.conv1.prec != PREC_F32 && force_tile == 0 && (!B.sc.W || xs16) && ldx % 8 == 0) ? B.conv1.prec : 0;
   if (!fold && !wino1) {
     STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ss, h16));
     set_seg(a, 0, act1, B.kcin, 0, B.conv1);
@@ -989,7 +988,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   if (R > 4096 && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
   // 16-bit modes, large batches: rounded copies of the blocks' inputs for the learned shortcuts, ping-pong like xa / xb: a block's
   // conv2 epilogue writes the hidden columns of the next block's copy, the constant columns (asr_res, F0, N) are rounded once
-  const bool x16 = R >= kRows16 && c->prec != PREC_F32 && d.dec_hidden % 8 == 0;
+  const bool x16 = R >= rows16_threshold() && c->prec != PREC_F32 && d.dec_hidden % 8 == 0;
   unsigned short* xs16a = x16 ? ws.get<unsigned short>(R * ldcat) : nullptr;
   unsigned short* xs16b = x16 ? ws.get<unsigned short>(R * ldcat) : nullptr;
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
@@ -1358,7 +1357,7 @@ inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows
 
 // prior convs (generator.py:412-413) write straight into the concat slots [h, h+hp) of the two head inputs.  The two
 // convs are independent (and independent of decoder/flow), so the caller may put them on different streams.
-inline bool vocoder_rows16(const stts_ctx* c, long rows) { return c->prec != PREC_F32 && rows >= kRows16; }
+inline bool vocoder_rows16(const stts_ctx* c, long rows) { return c->prec != PREC_F32 && rows >= rows16_threshold(); }
 
 // 16-bit operand modes, large batches: the head inputs are 16-bit row buffers (`head` reinterpreted, [rows, hc] elements) and
 // the conv reads a rounded copy of har (har16: scratch of rows * ld_har elements).
