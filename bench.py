@@ -367,13 +367,15 @@ def main():
         },
     }
 
-    if rank == 0 and world == 1 and not args.pmc_child:
+    if rank == 0 and not args.pmc_child:
         # ---- roofline leg: HIP events around every launch of the step (same stream), 3 steps right after the timed region
+        # (rank 0's own frame path, without the collection of the waveforms: the other ranks wait at the barrier below)
         lib = _lib.load()
         psteps = 3
         lib.stts_profile_begin()
         for _ in range(psteps):
-            step()
+            model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
+                             batch_scope=True, out=audio)
         buf = C.create_string_buffer(1 << 16)
         _lib.check(lib.stts_profile_report(C.c_void_p(torch.cuda.current_stream().cuda_stream), buf, len(buf)))
         recs = json.loads(buf.value.decode())
@@ -417,8 +419,8 @@ def main():
             "all_kernel_ms_per_step": round(all_ms / psteps, 4),
             "us_per_launch": round(1e3 * all_ms / max(all_n, 1), 2),
         }
-        # ---- CPU baseline leg: the oracle (validated against reference goldens) on the host cores
-        if not args.no_cpu_baseline:
+        # ---- CPU baseline leg: the oracle (validated against reference goldens) on the host cores (N = 1 only)
+        if world == 1 and not args.no_cpu_baseline:
             from oracle import stylish_oracle as O
 
             h = inp["host"]
@@ -449,6 +451,8 @@ def main():
             }
     if rank == 0 and not args.pmc_child:
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()  # rank 0's roofline leg is over
     model.close()
     if world > 1:
         dist.destroy_process_group()
