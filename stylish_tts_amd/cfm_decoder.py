@@ -91,16 +91,69 @@ class CfmMelDecoder:
         return y
 
     @torch.no_grad()
-    def forward(self, asr, F0, N, spk_emb, n_timesteps, temperature, z=None, sine_noise=None):
-        """sine_noise: optional list of per-step draws ([B, n, 1] each) replacing the estimator's own randn."""
+    def forward(self, asr, F0, N, spk_emb, n_timesteps, temperature, z=None, sine_noise=None, graph=False):
+        """sine_noise: optional list of per-step draws ([B, n, 1] each) replacing the estimator's own randn.
+        graph=True: the ~250 launches of one estimator evaluation are captured once into a HIP graph and replayed per Euler step
+        (the loop is launch-bound at small batches); same kernels, same arithmetic."""
         b, _, n = asr.shape
         if z is None:
             z = torch.rand((b, self.feat_dim, n), device=self.device)  # (uniform, as the reference draws it, :402)
         z = z.to(self.device, torch.float32)
+        if graph:
+            return self._forward_graph(asr, F0, N, spk_emb, n_timesteps, temperature, z, sine_noise)
         if sine_noise is None:
             return self.sampler(z, None, n_timesteps, temperature, asr=asr, F0=F0, N=N, spk_emb=spk_emb)
         it = iter(sine_noise)
         est = lambda x, t, mask=None, **kw: self._forward(x, t=t, mask=mask, sine_noise=next(it), **kw)  # noqa: E731
         return CfmSampler(est, non_drop_conds=["spk_emb"])(z, None, n_timesteps, temperature, asr=asr, F0=F0, N=N, spk_emb=spk_emb)
+
+    def _forward_graph(self, asr, F0, N, spk_emb, n_timesteps, temperature, z, sine_noise):
+        f32 = lambda a: a.detach().to(self.device, torch.float32).contiguous()  # noqa: E731
+        asr, F0, N, spk_emb = map(f32, (asr, F0, N, spk_emb))
+        B, _, n = asr.shape
+        seg, cseg = Segments([n] * B, self.device), Segments([F0.shape[-1]] * B, self.device)
+        x = self._rows(f32(z) * temperature, self.feat_dim)            # the state stays in time-major rows for the whole solve
+        asr_r = self._rows(asr, (asr.shape[1] + 31) // 32 * 32)
+        f0, nc = F0.reshape(-1), N.reshape(-1)
+        t_buf = torch.zeros(B, dtype=torch.float32, device=self.device)
+        nz_buf = torch.zeros(B * n, dtype=torch.float32, device=self.device)
+        draws = None if sine_noise is None else iter(sine_noise)
+
+        def next_noise():
+            if draws is None:
+                nz_buf.normal_()
+            else:
+                nz_buf.copy_(f32(next(draws)).reshape(-1))
+
+        # one eager evaluation first, ON THE CAPTURE STREAM: lazily created library state (the zero page, the split-K scratch, which is
+        # kept per launch stream) must exist before capture - an allocation during capture invalidates it
+        next_noise()
+        caller = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(caller)
+        with torch.cuda.stream(side):
+            v = self.estimator_packed(seg, x, asr_r, f0, nc, cseg, spk_emb, t_buf, nz_buf)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            v_static = self.estimator_packed(seg, x, asr_r, f0, nc, cseg, spk_emb, t_buf, nz_buf)
+        caller.wait_stream(side)
+        v.record_stream(caller)
+        ts = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)  # CfmSampler.solve_euler's grid and update order (cfm.py:65-84)
+        t, dt = ts[0].clone(), ts[1] - ts[0]
+        for step in range(1, len(ts)):
+            t_buf.fill_(float(t))
+            if step == 1:
+                v_use = v  # the eager evaluation above already is step 1 (t = 0, the first draw)
+            else:
+                next_noise()
+                g.replay()
+                v_use = v_static
+            _lib.check(self.lib.stts_euler_step(_stream(), _ptr(x), _ptr(v_use), C.c_float(float(dt)), x.numel()))
+            t = t + dt
+            if step < len(ts) - 1:
+                dt = ts[step + 1] - t
+        y = torch.empty(B, self.feat_dim, n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.stts_to_channel_major(_stream(), _ptr(x), self.feat_dim, B, self.feat_dim, n, _ptr(y)))
+        return y
 
     __call__ = forward

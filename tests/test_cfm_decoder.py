@@ -149,3 +149,20 @@ def test_hip_estimator_at_the_model_config_size():
     y = m._forward(d(x), d(asr), d(f0), d(nc), d(spk), d(t), sine_noise=d(nz)).cpu().numpy()
     ref = O.cfm_mel_decoder_forward(x, asr, f0, nc, spk, t, nz, sd, dims)
     assert np.abs(y - ref).max() < 1e-4 * np.abs(ref).max(), np.abs(y - ref).max()
+
+
+@pytest.mark.gpu
+def test_hip_graph_sampling_equals_eager_sampling():
+    """forward(graph=True): the estimator captured into a HIP graph and replayed per Euler step gives the eager result bit for bit."""
+    import torch
+
+    g, dims = load_golden("cfm_decoder"), CASES["small"]
+    m = _hip(dims)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    steps = int(g["sample_steps"])
+    args = (d(g["small_asr"]), d(g["small_f0"]), d(g["small_n"]), d(g["small_spk"]), steps, float(g["sample_temperature"]))
+    nzs = [d(g[f"sample_nz{i}"]) for i in range(steps)]
+    eager = m(*args, z=d(g["sample_z"]), sine_noise=nzs)
+    graph = m(*args, z=d(g["sample_z"]), sine_noise=nzs, graph=True)
+    assert torch.equal(eager, graph)
+    assert np.abs(graph.cpu().numpy() - g["sample_y"]).max() < 1e-4 * np.abs(g["sample_y"]).max()

@@ -27,4 +27,13 @@ for B, n in ((1, 240), (8, 240), (32, 240), (8, 800)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m(asr, f0, nc, spk, steps, 1.0)
     torch.cuda.synchronize(); sm = time.perf_counter() - t0
-    print(f"B={B:3d} x {n} frames ({B * n / 80:.0f} s of mel at 80 frames/s): {ev * 1e3:7.2f} ms per evaluation, {sm * 1e3:7.1f} ms per {steps}-step sampling = {B * n / 80 / sm:7.0f}x real time")
+    m(asr, f0, nc, spk, steps, 1.0, graph=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m(asr, f0, nc, spk, steps, 1.0, graph=True)
+    torch.cuda.synchronize(); sg = time.perf_counter() - t0
+    steps2 = 32
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m(asr, f0, nc, spk, steps2, 1.0, graph=True)
+    torch.cuda.synchronize(); sg2 = time.perf_counter() - t0
+    print(f"B={B:3d} x {n} frames ({B * n / 80:.0f} s of mel at 80 frames/s): {ev * 1e3:7.2f} ms per evaluation, {sm * 1e3:7.1f} ms per {steps}-step sampling = {B * n / 80 / sm:7.0f}x real time;"
+          f" HIP graph: {sg * 1e3:7.1f} ms ({B * n / 80 / sg:7.0f}x), {steps2} steps {sg2 * 1e3:7.1f} ms = {(sg2 - sg) / (steps2 - steps) * 1e3:.2f} ms per replayed step")
