@@ -134,25 +134,52 @@ __global__ void __launch_bounds__(64) cfm_source_kernel(const float* __restrict_
 
 // RMSNorm (eps 1e-6, xut/norm.py:25-40) + shared AdaLN modulation (xut/adaln.py:19-27): y = x / rms(x) * w * (scale_u + 1) + shift_u.
 // ada: [n_utt][3 C] = scale | shift | gate.  One wave per row; grid (row groups of 4, n_utt).
+// With T != nullptr the row first receives the previous branch's gated residual, x = X + T * (gate_prev_u + 1) (transformer.py:67-79:
+// X is the NORMALISED tensor that branch was fed with), so a branch's residual add and the next branch's norm are one launch;
+// Xout (optional) keeps x itself (the value a later cross-attention or the output projection reads).  Y may alias X.
 __global__ void __launch_bounds__(256) rms_adaln_kernel(const float* __restrict__ X, int ldx, int C, const float* __restrict__ w, const float* __restrict__ ada,
-                                                        const int* __restrict__ seg_off, float* __restrict__ Y, int ldy) {
+                                                        const int* __restrict__ seg_off, float* __restrict__ Y, int ldy, const float* __restrict__ T,
+                                                        const float* __restrict__ ada_prev, float* __restrict__ Xout) {
   const int u = blockIdx.y, lane = threadIdx.x & 63;
   const int lo = seg_off[u], n = seg_off[u + 1] - lo;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const float* x = X + (long)(lo + r) * ldx;
+  const float* t = T ? T + (long)(lo + r) * C : nullptr;
+  const float* gp = T ? ada_prev + (long)u * 3 * C + 2 * C : nullptr;
+  constexpr int kMaxPer = 16;  // C <= 1024
+  float v[kMaxPer];
   float q = 0.f;
-  for (int c = lane; c < C; c += 64) q += x[c] * x[c];
+#pragma unroll
+  for (int i = 0; i < kMaxPer; ++i) {
+    const int c = lane + 64 * i;
+    float xv = 0.f;
+    if (c < C) {
+      xv = x[c];
+      if (t) xv += t[c] * (gp[c] + 1.0f);
+    }
+    v[i] = xv;
+    q += xv * xv;
+  }
   const float inv = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-6f);
   const float* a = ada + (long)u * 3 * C;
   float* y = Y + (long)(lo + r) * ldy;
-  for (int c = lane; c < C; c += 64) y[c] = (x[c] * inv * w[c]) * (a[c] + 1.0f) + a[C + c];
+  float* xo = Xout ? Xout + (long)(lo + r) * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < kMaxPer; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) {
+      if (xo) xo[c] = v[i];
+      y[c] = (v[i] * inv * w[c]) * (a[c] + 1.0f) + a[C + c];
+    }
+  }
 }
 
 // Axial RoPE with one position axis (xut/axial_rope.py:10-29,122-149) in place on a column block of H heads x d features:
 // position of row p of an n-row utterance = torch.linspace(-1, 1, n)[p]; pair i of head h turns by pos * freq[h][i]:
 //   (x0, x1) -> (x0 cos - x1 sin, x1 cos + x0 sin).
-__global__ void __launch_bounds__(256) axial_rope_kernel(float* __restrict__ X, int ldx, int col0, int heads, int d, const float* __restrict__ freq,
+// col1 >= 0: the same rotation also on the column block at col1 (queries and keys in one launch).
+__global__ void __launch_bounds__(256) axial_rope_kernel(float* __restrict__ X, int ldx, int col0, int col1, int heads, int d, const float* __restrict__ freq,
                                                          const int* __restrict__ seg_off) {
   const int u = blockIdx.y;
   const int lo = seg_off[u], n = seg_off[u + 1] - lo;
@@ -168,6 +195,12 @@ __global__ void __launch_bounds__(256) axial_rope_kernel(float* __restrict__ X, 
     const float a = x[0], b = x[1];
     x[0] = a * cs - b * sn;
     x[1] = b * cs + a * sn;
+    if (col1 >= 0) {
+      float* y = X + (long)(lo + p) * ldx + col1 + h * d + 2 * k;
+      const float a2 = y[0], b2 = y[1];
+      y[0] = a2 * cs - b2 * sn;
+      y[1] = b2 * cs + a2 * sn;
+    }
   }
 }
 
@@ -370,42 +403,47 @@ inline int cfm_estimator(stts_ctx* c, const CfmModel& M, hipStream_t st, const S
     STTS_TRY(run_small(st, M.ad3[k], tm, 4 * dim, 0, ada + (size_t)k * U * 3 * dim, 3 * dim, U));
   }
   const dim3 rgrid(ceil_div(s.max_len(), 4), U), egrid(std::max(1, std::min(1024, ceil_div(s.max_len() * (dim / 4), 256))), U);
-  auto rope = [&](float* X, int ldx, int col0, const float* fr) {
+  STTS_CHECK(dim <= 1024, "cfm_estimator: hidden_dim %d > 1024", dim);
+  auto rope2 = [&](float* X, int ldx, int col0, int col1, const float* fr) {  // queries and keys of a q | k | v buffer
     hipLaunchKernelGGL(axial_rope_kernel, dim3(std::max(1, std::min(1024, ceil_div(s.max_len() * heads * (d.head_dim / 2), 256))), U), dim3(256), 0, st, X, ldx, col0,
-                       heads, d.head_dim, fr, s.dev);
+                       col1, heads, d.head_dim, fr, s.dev);
   };
-  float* cur = h;
-  float* other = tmp;  // ping-pong: a block's result lands in the buffer that is not its input
+  // norm(x) for the next branch, fused with the gated residual of the branch that just finished (t != nullptr): hn <- adaln(hn + t * gate)
+  auto norm = [&](const float* x, const float* w, const float* a_next, const float* t, const float* a_prev, float* xout) {
+    hipLaunchKernelGGL(rms_adaln_kernel, rgrid, dim3(256), 0, st, x, dim, dim, w, a_next, s.dev, hn, dim, t, a_prev, xout);
+  };
+  const float* a_attn = ada;
+  const float* a_x = ada + (size_t)1 * U * 3 * dim;
+  const float* a_mlp = ada + (size_t)2 * U * 3 * dim;
+  float* const other = tmp;  // the finished branch's projection; its gated residual is applied by the next norm launch
   for (size_t b = 0; b < M.blocks.size(); ++b) {
     const XutBlockW& B = M.blocks[b];
-    // self-attention branch
-    hipLaunchKernelGGL(rms_adaln_kernel, rgrid, dim3(256), 0, st, cur, dim, dim, B.n_attn, ada, s.dev, hn, dim);
+    // self-attention branch (its input norm also closes the previous block's SwiGLU branch)
+    if (b == 0) norm(h, B.n_attn, a_attn, nullptr, nullptr, nullptr);
+    else norm(hn, B.n_attn, a_attn, other, a_mlp, M.role[b - 1] == 1 ? ctx : nullptr);  // an encoder level's output is remembered (the newest wins)
     STTS_TRY(cfm_linear(st, s, hn, dim, B.qkv, ACT_NONE, qkv, 3 * dim));
-    rope(qkv, 3 * dim, 0, B.rope);
-    rope(qkv, 3 * dim, dim, B.rope);
+    rope2(qkv, 3 * dim, 0, dim, B.rope);
     STTS_TRY(run_attention(st, s, s, qkv, 3 * dim, 0, qkv, 3 * dim, dim, qkv, 3 * dim, 2 * dim, att, dim, heads, d.head_dim, nullptr, 0));
     STTS_TRY(cfm_linear(st, s, att, dim, B.out, ACT_NONE, other, dim));
-    hipLaunchKernelGGL(gated_residual_kernel, egrid, dim3(256), 0, st, hn, other, dim, ada, s.dev, cur);
+    const float* a_prev = a_attn;
     if (B.cross) {  // cross-attention to the last encoder level's output (xut.py:199-203: self_ctx[-1] for every decoder level)
-      const float* ax = ada + (size_t)1 * U * 3 * dim;
-      hipLaunchKernelGGL(rms_adaln_kernel, rgrid, dim3(256), 0, st, cur, dim, dim, B.n_xattn, ax, s.dev, hn, dim);
+      norm(hn, B.n_xattn, a_x, other, a_prev, nullptr);
       STTS_TRY(cfm_linear(st, s, hn, dim, B.xq, ACT_NONE, qkv, 3 * dim));            // q -> columns [0, dim)
       STTS_TRY(cfm_linear(st, s, ctx, dim, B.xkv, ACT_NONE, qkv + dim, 3 * dim));     // k | v -> columns [dim, 3 dim)
-      rope(qkv, 3 * dim, 0, B.xrope);
-      rope(qkv, 3 * dim, dim, B.xrope);
+      rope2(qkv, 3 * dim, 0, dim, B.xrope);
       STTS_TRY(run_attention(st, s, s, qkv, 3 * dim, 0, qkv, 3 * dim, dim, qkv, 3 * dim, 2 * dim, att, dim, heads, d.head_dim, nullptr, 0));
       STTS_TRY(cfm_linear(st, s, att, dim, B.xout, ACT_NONE, other, dim));
-      hipLaunchKernelGGL(gated_residual_kernel, egrid, dim3(256), 0, st, hn, other, dim, ax, s.dev, cur);
+      a_prev = a_x;
     }
     // SwiGLU branch
-    const float* am = ada + (size_t)2 * U * 3 * dim;
-    hipLaunchKernelGGL(rms_adaln_kernel, rgrid, dim3(256), 0, st, cur, dim, dim, B.n_mlp, am, s.dev, hn, dim);
+    norm(hn, B.n_mlp, a_mlp, other, a_prev, nullptr);
     STTS_TRY(cfm_linear(st, s, hn, dim, B.w12, ACT_NONE, a12, 2 * mlp));
     hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)std::min<long>(2048, ceil_div(R * (mlp / 4), 256L))), dim3(256), 0, st, a12, mlp, um, R);
     STTS_TRY(cfm_linear(st, s, um, mlp, B.w3, ACT_NONE, other, dim));
-    hipLaunchKernelGGL(gated_residual_kernel, egrid, dim3(256), 0, st, hn, other, dim, am, s.dev, cur);
-    if (M.role[b] == 1) STTS_HIP(hipMemcpyAsync(ctx, cur, R * dim * sizeof(float), hipMemcpyDeviceToDevice, st));  // the newest encoder level wins
   }
+  // the last block's SwiGLU residual: x = hn + other * (gate + 1)
+  float* cur = h;
+  hipLaunchKernelGGL(gated_residual_kernel, egrid, dim3(256), 0, st, hn, other, dim, a_mlp, s.dev, cur);
   STTS_TRY(cfm_linear(st, s, cur, dim, M.out_proj, ACT_NONE, out, ld_out));
   STTS_HIP(hipGetLastError());
   return 0;
