@@ -389,6 +389,95 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------
+// ConvNeXt front half in one launch (models/generator.py:449-462): depthwise conv along time + adaptive LayerNorm over channels,
+//   y[r] = LN_C(dw(x)[r]) * (1 + gamma_u) + beta_u,
+// for C <= 512, K <= 7.  A block owns 16 rows x all channels: the rows + halo are staged in LDS once, the conv results replace
+// them there, and each wave normalises four of the rows - the intermediate [rows, C] tensor of the two-kernel form (one write +
+// one read of it, and one of two ~14-us launches at B = 8) disappears.  Per element the arithmetic and its order are those of
+// dwconv_kernel followed by row_layernorm_kernel (taps in order; lane-strided float4 sums, then the wave reduction).
+// ---------------------------------------------------------------------------------------------
+constexpr int kDwLnRows = 16, kDwLnMaxC = 512, kDwLnMaxK = 7;
+__global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
+                                                        const float* __restrict__ Wt, const float* __restrict__ bias, int K, float eps,
+                                                        const float* __restrict__ style, int ld_style, int gcol0, float* __restrict__ Y, int ldy,
+                                                        int prec16) {
+  __shared__ float tile[(kDwLnRows + kDwLnMaxK - 1) * kDwLnMaxC];
+  const int u = blockIdx.y;
+  const int lo = seg_off[u], hi = seg_off[u + 1];
+  const int r0 = lo + blockIdx.x * kDwLnRows;
+  if (r0 >= hi) return;
+  const int pad = (K - 1) / 2, nrows = kDwLnRows + K - 1, c4n = C / 4;
+  for (int i = threadIdx.x; i < nrows * c4n; i += 256) {
+    const int rr = i / c4n, c4 = (i % c4n) * 4;
+    const int g = r0 - pad + rr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g >= lo && g < hi) v = *reinterpret_cast<const float4*>(X + (long)g * ldx + c4);
+    *reinterpret_cast<float4*>(&tile[rr * C + c4]) = v;
+  }
+  __syncthreads();
+  // depthwise conv: thread = channels tid, tid + 256 (C <= 512), all 16 rows
+  float acc[2][kDwLnRows];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = threadIdx.x + 256 * h;
+    if (c < C) {
+      const float bv = bias[c];
+#pragma unroll
+      for (int i = 0; i < kDwLnRows; ++i) acc[h][i] = bv;
+      for (int k = 0; k < K; ++k) {
+        const float w = Wt[(long)k * C + c];
+#pragma unroll
+        for (int i = 0; i < kDwLnRows; ++i) acc[h][i] += w * tile[(i + k) * C + c];
+      }
+    }
+  }
+  __syncthreads();  // every tap has been read: the conv results take the place of the first 16 rows
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = threadIdx.x + 256 * h;
+    if (c < C)
+#pragma unroll
+      for (int i = 0; i < kDwLnRows; ++i) tile[i * C + c] = acc[h][i];
+  }
+  __syncthreads();
+  // LayerNorm: wave w takes rows w, w + 4, ...
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* gp0 = style + (long)u * ld_style + gcol0;
+  for (int i = wv; i < kDwLnRows; i += 4) {
+    const int r = r0 + i;
+    if (r >= hi) break;
+    float4 v[2];
+    float sum = 0.f;
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int q = lane + 64 * q2;
+      v[q2] = q < c4n ? *reinterpret_cast<const float4*>(&tile[i * C + q * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sum += v[q2].x + v[q2].y + v[q2].z + v[q2].w;
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+      if (lane + 64 * q2 < c4n) {
+        const float a = v[q2].x - mean, b = v[q2].y - mean, c = v[q2].z - mean, d = v[q2].w - mean;
+        ss += a * a + b * b + c * c + d * d;
+      }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int q = lane + 64 * q2;
+      if (q < c4n) {
+        float4 g = *reinterpret_cast<const float4*>(gp0 + q * 4);
+        const float4 b = *reinterpret_cast<const float4*>(gp0 + C + q * 4);
+        g.x += 1.f; g.y += 1.f; g.z += 1.f; g.w += 1.f;
+        store4(Y, (long)r * ldy + q * 4, (v[q2].x - mean) * rstd * g.x + b.x, (v[q2].y - mean) * rstd * g.y + b.y, (v[q2].z - mean) * rstd * g.z + b.z,
+               (v[q2].w - mean) * rstd * g.w + b.w, prec16);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // GRN (models/generator.py:496-499): Gx[u][c] = ||U[:, c]||_2 over the utterance's rows (from the per-tile
 // partial sums the pwconv1 GEMM epilogue wrote), Nx = Gx / (mean_c Gx + 1e-6).  GRN(U) = U*(gamma*Nx + 1) + beta
 // is folded into pwconv2:  W2_u[co][c] = W2[co][c] * (gamma[c]*Nx[u][c] + 1)   (beta goes into the bias at load).

@@ -1440,10 +1440,16 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   float* nxt = xb;
   for (int i = 0; i < 4; ++i) {
     const ConvNextW& B = c->cnx[i];
-    STTS_LAUNCH_PROF("dwconv_kernel", (size_t)R * h * 2 * 4, (dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), st, cur, h, dw, h, h, s.dev, B.dw_wt,
-                       B.dw_b, B.K, (int)ACT_NONE);
-    LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0, p16}, o1{};
-    STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE));
+    if (h <= kDwLnMaxC && h % 4 == 0 && B.K <= kDwLnMaxK) {
+      // depthwise conv + adaptive LayerNorm in one launch (the [rows, h] intermediate never reaches HBM)
+      STTS_LAUNCH_PROF("dwconv_ln_kernel", (size_t)R * h * (4 + (p16 ? 2 : 4)), dwconv_ln_kernel, dim3(ceil_div(ml, kDwLnRows), s.n_utt), dim3(256), st, cur, h, h, s.dev,
+                         B.dw_wt, B.dw_b, B.K, 1e-6f, sty, lds, B.norm.col0, nrm, h, p16);
+    } else {
+      STTS_LAUNCH_PROF("dwconv_kernel", (size_t)R * h * 2 * 4, (dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), st, cur, h, dw, h, h, s.dev, B.dw_wt,
+                         B.dw_b, B.K, (int)ACT_NONE);
+      LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0, p16}, o1{};
+      STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE));
+    }
     GemmArgs a = gemm_args(s);
     set_seg(a, 0, nrm, h, 0, B.pw1);
     a.N = inter; a.bias = B.pw1.bias; a.act = ACT_SILU;
