@@ -391,23 +391,28 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ X
 // ---------------------------------------------------------------------------------------------
 // ConvNeXt front half in one launch (models/generator.py:449-462): depthwise conv along time + adaptive LayerNorm over channels,
 //   y[r] = LN_C(dw(x)[r]) * (1 + gamma_u) + beta_u,
-// for C <= 512, K <= 7.  A block owns 16 rows x all channels: the rows + halo are staged in LDS once, the conv results replace
-// them there, and each wave normalises four of the rows - the intermediate [rows, C] tensor of the two-kernel form (one write +
-// one read of it, and one of two ~14-us launches at B = 8) disappears.  Per element the arithmetic and its order are those of
-// dwconv_kernel followed by row_layernorm_kernel (taps in order; lane-strided float4 sums, then the wave reduction).
+// for C <= 512 and the kernel sizes the generator uses (template K).  A block owns 16 rows x all channels: the rows + halo are
+// staged in LDS once, every thread pulls the 16 + K - 1 inputs of its channels into registers ONCE (the two-kernel form reads
+// K values from LDS per output: at K = 31 that, not HBM, is what bounds it), the conv results replace the staged rows, and each
+// wave normalises four of them - the intermediate [rows, C] tensor (one write + one read, and one of two launches) disappears.
+// Per element the arithmetic and its order are those of dwconv_kernel followed by row_layernorm_kernel (taps in order;
+// lane-strided float4 sums, then the wave reduction).
 // ---------------------------------------------------------------------------------------------
-constexpr int kDwLnRows = 16, kDwLnMaxC = 512, kDwLnMaxK = 7;
+constexpr int kDwLnRows = 16, kDwLnMaxC = 512;
+template <int K>
 __global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
-                                                        const float* __restrict__ Wt, const float* __restrict__ bias, int K, float eps,
+                                                        const float* __restrict__ Wt, const float* __restrict__ bias, float eps,
                                                         const float* __restrict__ style, int ld_style, int gcol0, float* __restrict__ Y, int ldy,
                                                         int prec16) {
-  __shared__ float tile[(kDwLnRows + kDwLnMaxK - 1) * kDwLnMaxC];
+  constexpr int NR = kDwLnRows + K - 1;
+  __shared__ float tile[NR * kDwLnMaxC];
   const int u = blockIdx.y;
   const int lo = seg_off[u], hi = seg_off[u + 1];
   const int r0 = lo + blockIdx.x * kDwLnRows;
   if (r0 >= hi) return;
-  const int pad = (K - 1) / 2, nrows = kDwLnRows + K - 1, c4n = C / 4;
-  for (int i = threadIdx.x; i < nrows * c4n; i += 256) {
+  constexpr int pad = (K - 1) / 2;
+  const int c4n = C / 4;
+  for (int i = threadIdx.x; i < NR * c4n; i += 256) {
     const int rr = i / c4n, c4 = (i % c4n) * 4;
     const int g = r0 - pad + rr;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -415,23 +420,27 @@ __global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(&tile[rr * C + c4]) = v;
   }
   __syncthreads();
-  // depthwise conv: thread = channels tid, tid + 256 (C <= 512), all 16 rows
+  // depthwise conv: thread = channels tid, tid + 256 (C <= 512), all 16 rows, inputs held in a register window
   float acc[2][kDwLnRows];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int c = threadIdx.x + 256 * h;
     if (c < C) {
+      float win[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) win[i] = tile[i * C + c];
       const float bv = bias[c];
 #pragma unroll
       for (int i = 0; i < kDwLnRows; ++i) acc[h][i] = bv;
+#pragma unroll
       for (int k = 0; k < K; ++k) {
         const float w = Wt[(long)k * C + c];
 #pragma unroll
-        for (int i = 0; i < kDwLnRows; ++i) acc[h][i] += w * tile[(i + k) * C + c];
+        for (int i = 0; i < kDwLnRows; ++i) acc[h][i] += w * win[i + k];
       }
     }
   }
-  __syncthreads();  // every tap has been read: the conv results take the place of the first 16 rows
+  __syncthreads();  // every input has been read: the conv results take the place of the first 16 rows
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int c = threadIdx.x + 256 * h;

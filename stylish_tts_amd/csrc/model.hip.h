@@ -1440,10 +1440,16 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   float* nxt = xb;
   for (int i = 0; i < 4; ++i) {
     const ConvNextW& B = c->cnx[i];
-    if (h <= kDwLnMaxC && h % 4 == 0 && B.K <= kDwLnMaxK) {
+    if (h <= kDwLnMaxC && h % 4 == 0 && (B.K == 3 || B.K == 7 || B.K == 15 || B.K == 31)) {
       // depthwise conv + adaptive LayerNorm in one launch (the [rows, h] intermediate never reaches HBM)
-      STTS_LAUNCH_PROF("dwconv_ln_kernel", (size_t)R * h * (4 + (p16 ? 2 : 4)), dwconv_ln_kernel, dim3(ceil_div(ml, kDwLnRows), s.n_utt), dim3(256), st, cur, h, h, s.dev,
-                         B.dw_wt, B.dw_b, B.K, 1e-6f, sty, lds, B.norm.col0, nrm, h, p16);
+      const dim3 fg(ceil_div(ml, kDwLnRows), s.n_utt);
+      const size_t fb = (size_t)R * h * (4 + (p16 ? 2 : 4));
+#define STTS_DWLN(KK) STTS_LAUNCH_PROF("dwconv_ln_kernel", fb, dwconv_ln_kernel<KK>, fg, dim3(256), st, cur, h, h, s.dev, B.dw_wt, B.dw_b, 1e-6f, sty, lds, B.norm.col0, nrm, h, p16)
+      if (B.K == 3) STTS_DWLN(3);
+      else if (B.K == 7) STTS_DWLN(7);
+      else if (B.K == 15) STTS_DWLN(15);
+      else STTS_DWLN(31);
+#undef STTS_DWLN
     } else {
       STTS_LAUNCH_PROF("dwconv_kernel", (size_t)R * h * 2 * 4, (dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), st, cur, h, dw, h, h, s.dev, B.dw_wt,
                          B.dw_b, B.K, (int)ACT_NONE);
