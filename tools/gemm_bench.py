@@ -13,6 +13,7 @@ shapes = [  # name, cin, cout, k
     ("prior 1025->256 k7", 1025, 256, 7), ("flow in 128->256 k5", 128, 256, 5), ("flow rs 128->256", 128, 256, 1),
     ("square 4096 (1 utt)", 4096, 4096, 1),
     ("wino plane 768->1024 k1", 768, 1024, 1), ("wino plane 608->512 k1", 608, 512, 1),  # B=20 / B=12 x 960 rows = the component planes at B=8
+    ("small asr_res 128->64", 128, 64, 1), ("small prior 512->256", 512, 256, 1), ("small pre 64->128", 64, 128, 1), ("small post_flow 128->512", 128, 512, 1),
 ]
 B, T4 = int(os.environ.get("B", 8)), int(os.environ.get("T4", 960))
 flt = os.environ.get("SHAPES")
