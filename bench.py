@@ -1,77 +1,136 @@
 #!/usr/bin/env python3
-"""bench.py — utterances/s and RTF of the frame-rate hot path on MI355X (BASELINE.json cfg2).
+"""bench.py — utterances/s and RTF of the Stylish-TTS inference hot path on MI355X (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (`stts_frame_path`: Decoder → PriorEncoder + reverse flow + post_flow →
-harmonic source → STFT → vocoder body → iSTFT → tanh) over one batch of 8 synthetic LJSpeech-shaped utterances
-of 3.0 s (T = 240 mel frames, T4 = 960 vocoder frames, 72 000 samples) in fp32, inputs resident in HBM.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); rank 0 broadcasts the packed weights once,
-every rank runs its own batch (weak scaling, utterances are independent) and the waveforms are gathered to rank 0
-inside the timed step.  Rank 0 prints ONE JSON line.
+The bench line (`value`): BASELINE cfg2 — one step = one pass of `stts_frame_path` (Decoder → PriorEncoder + reverse flow +
+post_flow → harmonic source → STFT → vocoder body → iSTFT → tanh) over 8 synthetic LJSpeech-shaped utterances of 3.0 s per GPU
+(T = 240 mel frames, T4 = 960 vocoder frames, 72 000 samples) in fp32, inputs resident in HBM; weak scaling over the GPUs.
 
-Extra legs (rank 0, N = 1):
-  * `roofline`: HIP start/stop events on EVERY launch of the step (its own stream) in a profiling pass right after the timed
-    region (`stts_profile_begin/report`): the dense contractions (conv_gemm_f32, the Winograd-form convs, the fused WaveNet
-    kernel) against the MFMA roof, in algorithmic (direct-conv) flops AND in the flops the matrix cores execute; the
-    bandwidth-bound kernels (`hbm_kernels`) against 8 TB/s with their algorithmic bytes; launches and
-    microseconds per launch of the whole step.
-  * `roofline.traffic`: HBM-side bytes per contraction launch from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE)
-    over this same script, run as child processes BEFORE this process touches the GPU; null when rocprofv3 is missing.
-  * `cpu_baseline`: the numpy oracle timed on the host cores on a bounded sample of the same workload.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Under `python -m torch.distributed.run` the ranks are given;
+invoked plainly as `python bench.py --gpus N` this process is a GPU-free PARENT that compiles the library, starts the N ranks as
+child processes (stylish_tts_amd/launcher.py), relays rank 0's JSON line and exits with the ranks' status.  Rank 0 broadcasts the
+weights once; per step every rank runs its shard and the waveforms are collected on rank 0 (exact-size point-to-point transfers)
+inside the timed region.  Rank 0 prints ONE JSON line.
+
+Besides the bench line the same JSON carries (skipped with --no-legs):
+  * `legs.cfg4_strong` / `legs.cfg5_strong`: BASELINE configs[3] / [4] as ONE fixed global batch (256 utterances of 0.25-10 s in fp32;
+    512 segments of 10 s with fp16 operands) partitioned over the ranks by frame count — the strong-scaling numbers;
+  * `legs.cfg3_full_chain`: BASELINE configs[2] — tokens → waveform through the whole chain (duration + pitch/energy predictors in
+    fp32, frame path with bf16 operands) at 64 utterances of 50 tokens per GPU, with the phoneme-rate / frame-rate split;
+  * `roofline`: HIP start/stop events on EVERY launch of the step in a profiling pass right after the timed region
+    (`stts_profile_begin/report`): the dense contractions against the MFMA roof in algorithmic (direct-conv) flops AND in executed
+    flops, calibrated against the un-instrumented step (event pairs on every launch stretch the step by some per cent); the
+    bandwidth-bound kernels against 8 TB/s with their algorithmic bytes; `traffic`: HBM-side bytes per contraction
+    launch from two `rocprofv3 --pmc` child passes that run BEFORE this process touches the GPU;
+  * `cpu_baseline`: the numpy oracle on the host cores, a pool of worker processes over utterances (N = 1, before the GPU is touched).
+`--workload cfg3 | cfg4 | cfg5` makes that configuration the (only) timed workload of the run.
 """
 from __future__ import annotations
 
 import argparse
-import csv
-import ctypes as C
-import glob
 import json
 import os
-import shutil
-import subprocess
 import sys
-import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-BATCH, T_MEL, SR = 8, 240, 24000
-T4 = 4 * T_MEL
+SR = 24000
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 MFMA_PEAK_TFLOPS = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": 2500.0, "f16": 2500.0}  # dense 16-bit MFMA (same guide)
+FRAME_MFLOP = 74.1           # frame-rate part, MFLOP per hop-75 frame
+PHONEME_GFLOP_PER_TOKEN = 3.6 / 50.0  # ~3.6 GFLOP per 50-token utterance (text encoders, duration head, pitch/energy)
+CONTRACTION_KERNELS = ("conv_gemm", "wn_fused", "wn_layer", "winograd_", "gemm16")
+MAX_ROWS_PER_CALL = 220_000  # frames per stts_frame_path call (~12 GB of workspace; 64 x 10 s = 204 800 is the size the tests pin)
+
+WORKLOADS = {
+    # BASELINE.json configs[3]: 256 utterances of 0.25-10 s (seeded), fp32, one fixed global batch sharded over the ranks
+    "cfg4": dict(n_utt=256, seconds=(0.25, 10.0), precision="f32", note="mixed-length batch: 256 utterances of 0.25-10 s"),
+    # BASELINE.json configs[4]: 512 segments of 10 s, fp16 operands (the speaker-id input does not exist in the reference: SURVEY.md 8c)
+    "cfg5": dict(n_utt=512, seconds=(10.0, 10.0), precision="f16", note="long-form batch: 512 segments of 10 s (single-speaker graph: the reference has no speaker-id embedding)"),
+}
 
 
-def synth_inputs(rank: int, device):
+# ------------------------------------------------------------------------------------------------ CPU baseline (no GPU, worker pool)
+def _cpu_worker_init(threads: int):
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = str(threads)
+    global _W
+    import numpy as np  # noqa: F401
+
+    from stylish_tts_amd import params
+    from stylish_tts_amd.config import load_model_config
+
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(threads)
+    except Exception:
+        pass
+    _W = params.synth_state_dict(params.module_spec("speech_predictor", load_model_config()), 0, prefix="speech_predictor.")
+
+
+def _cpu_worker_run(job):
+    """One utterance of the bench workload through the oracle's frame path (B = 1, the way the reference's callers run it)."""
+    import numpy as np
+
+    from oracle import stylish_oracle as O
     from stylish_tts_amd import synth
 
-    tag = f"bench.r{rank}"
-    asr = np.concatenate([synth.normal(f"{tag}.asr{b}", (T4, 128)) for b in range(BATCH)])
-    pitch = np.concatenate([synth.pitch_curve(f"{tag}.pitch{b}", 1, T4)[0] for b in range(BATCH)])
-    energy = np.concatenate([(synth.uniform(f"{tag}.energy{b}", (T4,)) * 2 + 2).astype(np.float32) for b in range(BATCH)])
-    style = (synth.normal(f"{tag}.style", (BATCH, 64)) * 0.7).astype(np.float32)
-    nz = synth.path_noise(tag, BATCH, T4)
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
-    return dict(
-        asr=d(asr), pitch=d(pitch), energy=d(energy), style=d(style),
-        prior_noise=d(nz["prior_noise"].transpose(0, 2, 1).reshape(BATCH * T4, 128)),
-        src_noise=d(nz["src_noise"].reshape(-1)), init_phase=d(nz["init_phase"].reshape(-1)),
-        host=dict(asr=asr, pitch=pitch, energy=energy, style=style, nz=nz),
-    )
+    b, t4 = job
+    if b < 0:
+        return 0.0  # start-up barrier: the worker has imported everything and built its weights
+    tag = "bench.r0"
+    asr = synth.normal(f"{tag}.asr{b}", (t4, 128)).T[None].copy()
+    pitch = synth.pitch_curve(f"{tag}.pitch{b}", 1, t4)
+    energy = (synth.uniform(f"{tag}.energy{b}", (t4,)) * 2 + 2).astype(np.float32)[None]
+    style = (synth.normal(f"{tag}.style1.{b}", (1, 64)) * 0.7).astype(np.float32)
+    nz = synth.path_noise(f"{tag}.u{b}", 1, t4)
+    t0 = time.perf_counter()
+    O.frame_path(asr, pitch, energy, style, nz, _W)
+    return time.perf_counter() - t0
 
 
-CONTRACTION_KERNELS = ("conv_gemm_f32", "wn_fused_kernel", "wn_layer", "winograd_")
+def cpu_baseline(args, t4: int):
+    """The oracle (kind "port") on the host cores: `workers` processes x `threads` BLAS threads, utterances dealt over the workers.
+    Runs before this process touches the GPU (the workers are child processes)."""
+    import multiprocessing as mp
+
+    cores = os.cpu_count() or 1
+    share = min(cores, 16)  # the CPU share of a one-GPU box
+    threads = max(1, min(args.cpu_threads, share))
+    workers = max(1, min(args.cpu_workers or share // threads, args.cpu_utts))
+    n_utts = max(workers, args.cpu_utts // workers * workers)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=(threads,)) as pool:
+        pool.map(_cpu_worker_run, [(-1, t4)] * workers, chunksize=1)  # every worker is up
+        t0 = time.perf_counter()
+        per = pool.map(_cpu_worker_run, [(b % 8, t4) for b in range(n_utts)], chunksize=1)
+        wall = time.perf_counter() - t0
+    return {
+        "value": round(n_utts / wall, 4), "unit": "utt/s", "cores": workers * threads, "kind": "port",
+        "sample": f"{n_utts} utterances of the bench workload ({t4 * 75 / SR:.1f} s each) through the numpy oracle's frame path, one utterance per call like the "
+                  f"reference's callers; {workers} worker processes x {threads} BLAS threads = {workers * threads} of the host's {cores} logical cores; "
+                  f"{wall:.1f} s of wall time, {sum(per) / len(per):.2f} s per utterance per worker",
+        "reference_torch_cpu_note": "survey container, 8 vCPU, the reference's own torch-CPU code: 1.4 utt/s at B=1, 1.9-2.5 utt/s at B=8 (BASELINE.md §2)",
+    }
 
 
+# ------------------------------------------------------------------------------------------------ HBM traffic (rocprofv3 --pmc children)
 def measure_traffic(extra_args):
     """HBM-side bytes per contraction launch: two separate `rocprofv3 --pmc` passes over `bench.py --pmc-child` (child
-    processes, started before this process initialises the GPU).  Units and the gfx950 correction follow
-    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB, and FETCH_SIZE tallies 128-byte
-    requests at 64 bytes (x2).  Returns (bytes_per_launch or None, note)."""
+    processes, started before this process initialises the GPU; the library is already compiled, the children never compile).
+    Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB, and
+    FETCH_SIZE tallies 128-byte requests at 64 bytes (x2).  Returns (bytes_per_launch or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
@@ -101,49 +160,248 @@ def measure_traffic(extra_args):
                                                        "dispatch; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); L2-miss traffic incl. Infinity-Cache hits")
 
 
-WORKLOADS = {
-    # BASELINE.json configs[3]: 256 utterances of 0.25-10 s (seeded), fp32, one fixed global batch sharded over the ranks
-    "cfg4": dict(n_utt=256, seconds=(0.25, 10.0), precision="f32", note="mixed-length batch: 256 utterances of 0.25-10 s"),
-    # BASELINE.json configs[4]: 512 segments of 10 s, fp16 operands (the speaker-id input does not exist in the reference: SURVEY.md 8c)
-    "cfg5": dict(n_utt=512, seconds=(10.0, 10.0), precision="f16", note="long-form batch: 512 segments of 10 s"),
-}
-MAX_ROWS_PER_CALL = 220_000  # frames per stts_frame_path call (~12 GB of workspace; 64 x 10 s = 204 800 is the size the tests pin)
+# ------------------------------------------------------------------------------------------------ distributed context
+class Ctx:
+    def __init__(self, world, rank, local):
+        self.world, self.rank, self.local = world, rank, local
+        self.dist = None
+        self.device = None
+        self.backend = None
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        import torch
+
+        t = torch.tensor([v], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
 
-def run_sharded(args, world, rank, local, device, dist):
-    """--workload cfg4 | cfg5: ONE fixed global batch, utterances partitioned over the ranks by frame count (longest first),
-    every rank runs its shard through stts_frame_path (in calls of at most MAX_ROWS_PER_CALL frames) and the waveforms are
-    collected on rank 0 with exact sizes (sharding.WaveformCollector) inside the timed step.  Strong scaling: the work is
-    fixed, `value` = utterances of the global batch / step time."""
-    import __graft_entry__ as entry
+def timed_steps(ctx: Ctx, step, steps: int, warmup: int, after_warmup=None) -> float:
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+    import torch
 
-    if rank == 0:
-        entry.build()
-    if world > 1:
-        dist.barrier()
+    for _ in range(warmup):
+        step()
+    if after_warmup:
+        after_warmup()
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    return ctx.max_over_ranks(time.perf_counter() - t0)
+
+
+def device_identity(device) -> str:
+    import torch
+
+    p = torch.cuda.get_device_properties(device)
+    ident = getattr(p, "uuid", None)
+    return f"{p.name} #{device.index} {ident}" if ident is not None else f"{p.name} #{device.index}"
+
+
+def broadcast_weights(ctx: Ctx, names, cfg):
+    """{module: state dict} on every rank: rank 0 synthesizes, one flat fp32 broadcast per module (RCCL), once, outside the timed region."""
     from stylish_tts_amd import params
+    from stylish_tts_amd.sharding import broadcast_state_dict
+
+    out = {}
+    for m in names:
+        spec = params.module_spec(m, cfg)
+        sd = params.synth_state_dict(spec, 0, prefix=m + ".") if ctx.rank == 0 else None
+        if ctx.world > 1:
+            sd = broadcast_state_dict(sd, spec, ctx.device if ctx.backend == "nccl" else "cpu", src=0)
+        out[m] = sd
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ cfg2: the bench line
+def cfg2_inputs(rank: int, device, batch: int, t4: int):
+    import numpy as np
+    import torch
+
+    from stylish_tts_amd import synth
+
+    tag = f"bench.r{rank}"
+    asr = np.concatenate([synth.normal(f"{tag}.asr{b}", (t4, 128)) for b in range(batch)])
+    pitch = np.concatenate([synth.pitch_curve(f"{tag}.pitch{b}", 1, t4)[0] for b in range(batch)])
+    energy = np.concatenate([(synth.uniform(f"{tag}.energy{b}", (t4,)) * 2 + 2).astype(np.float32) for b in range(batch)])
+    style = (synth.normal(f"{tag}.style", (batch, 64)) * 0.7).astype(np.float32)
+    nz = synth.path_noise(tag, batch, t4)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
+    return dict(
+        asr=d(asr), pitch=d(pitch), energy=d(energy), style=d(style),
+        prior_noise=d(nz["prior_noise"].transpose(0, 2, 1).reshape(batch * t4, 128)),
+        src_noise=d(nz["src_noise"].reshape(-1)), init_phase=d(nz["init_phase"].reshape(-1)),
+    )
+
+
+def run_cfg2(ctx: Ctx, args, traffic, traffic_note):
+    import torch
+
     from stylish_tts_amd.config import load_model_config
     from stylish_tts_amd.runtime import HipModel, Segments
-    from stylish_tts_amd.sharding import WaveformCollector, broadcast_state_dict, partition_utterances
+    from stylish_tts_amd.sharding import WaveformCollector
 
-    wl = WORKLOADS[args.workload]
-    precision = wl["precision"] if args.precision == "f32" and args.workload == "cfg5" else args.precision
+    B, t4 = args.batch, 4 * args.mel_frames
     cfg = load_model_config()
-    spec = params.module_spec("speech_predictor", cfg)
-    sd = params.synth_state_dict(spec, 0, prefix="speech_predictor.") if rank == 0 else None
-    if world > 1:
-        sd = broadcast_state_dict(sd, spec, device, src=0)
-    model = HipModel(cfg, local, precision=precision)
-    model.load_weights({"speech_predictor": sd}, which=7)
+    w = broadcast_weights(ctx, ["speech_predictor"], cfg)
+    model = HipModel(cfg, ctx.local, precision=args.precision)
+    model.load_weights(w, which=7)
+    seg = Segments([t4] * B, ctx.device)
+    inp = cfg2_inputs(ctx.rank, ctx.device, B, t4)
+    audio = torch.empty(B * t4 * 75, dtype=torch.float32, device=ctx.device)
+    # global batch = world x B utterances; rank r owns utterances [r B, (r + 1) B): the collector is told that partition
+    col = WaveformCollector([75 * t4] * (B * ctx.world), ctx.device, dst=0, parts=[list(range(r * B, (r + 1) * B)) for r in range(ctx.world)]) if ctx.world > 1 else None
 
-    n_utt = args.utterances or wl["n_utt"]
+    def step():
+        model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
+                         batch_scope=True, out=audio)
+        if col is not None:
+            col.collect(audio)  # waveforms to rank 0 over xGMI, inside the timed step
+
+    elapsed = timed_steps(ctx, step, args.steps, args.warmup, after_warmup=model.check_status)
+    assert bool(torch.isfinite(audio).all())
+    utts = ctx.world * B * args.steps
+    audio_seconds = utts * (t4 * 75 / SR)
+    is_cfg2 = (B, args.mel_frames, args.precision) == (8, 240, "f32")
+    devices = ctx.gather_objects(device_identity(ctx.device))
+    out = {
+        "metric": "utterances_per_sec", "value": round(utts / elapsed, 3), "unit": "utt/s",
+        "rtf": elapsed / audio_seconds, "realtime_x": audio_seconds / elapsed,
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {
+            "workload": ("cfg2: " if is_cfg2 else "side experiment: ") + f"LJSpeech-shaped batch={B} x {args.mel_frames / 80:.1f} s per GPU (T={args.mel_frames} mel frames, {t4 * 75} samples @24 kHz) "
+                        + ("fp32" if args.precision == "f32" else f"{args.precision} matrix-core operands, fp32 accumulate")
+                        + ", Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); no diffusion step exists in the reference",
+            "batch_per_gpu": B, "global_batch": B * ctx.world, "frames_per_utt": t4,
+            "parallelism": (f"utterance-sharded x{ctx.world}: {ctx.backend} broadcast(weights, once) + exact-size point-to-point collection of the waveforms on rank 0 per step"
+                            if ctx.world > 1 else "single GPU"),
+            "ranks": ctx.world if ctx.world == 1 else ctx.dist.get_world_size(), "backend": ctx.backend or "none", "devices": devices,
+            "distinct_devices": len(set(devices)),
+            "frames_per_rank": [B * t4] * ctx.world, "imbalance_max_over_mean": 1.0,
+            "collect_bytes_per_step": 0 if ctx.world == 1 else 4 * 75 * t4 * B * (ctx.world - 1),
+        },
+    }
+    if not args.pmc_child:
+        out["roofline"] = roofline_leg(ctx, args, model, lambda: model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"],
+                                                                                 inp["src_noise"], inp["init_phase"], batch_scope=True, out=audio),
+                                       1e3 * elapsed / args.steps, traffic, traffic_note)
+    model.close()
+    return out
+
+
+def roofline_leg(ctx: Ctx, args, model, frame_step, ms_per_step, traffic, traffic_note, precision=None):
+    """HIP events around every launch of `frame_step` (same stream), 3 steps right after the timed region; every rank measures its own
+    GPU, rank 0's figures are reported with the spread over ranks.  Calibration: event pairs on every launch serialise the dispatches
+    and stretch the sum of the kernel durations beyond the un-instrumented step, so every duration is scaled by
+    (GPU time of the un-instrumented step) / (sum of the event-timed durations) when that ratio is below 1."""
+    import ctypes as C
+
+    import torch
+
+    from stylish_tts_amd import _lib
+
+    precision = precision or args.precision
+    lib = _lib.load()
+    psteps = 3
+    # GPU time of the plain step (one event pair around three whole steps, same stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    frame_step()
+    e0.record()
+    for _ in range(psteps):
+        frame_step()
+    e1.record()
+    torch.cuda.synchronize()
+    plain_ms = e0.elapsed_time(e1) / psteps
+    lib.stts_profile_begin()
+    for _ in range(psteps):
+        frame_step()
+    buf = C.create_string_buffer(1 << 17)
+    _lib.check(lib.stts_profile_report(C.c_void_p(torch.cuda.current_stream().cuda_stream), buf, len(buf)))
+    recs = json.loads(buf.value.decode())
+    peak = MFMA_PEAK_TFLOPS[precision]
+    con = [r for r in recs if r["kind"] == "contraction"]
+    oth = [r for r in recs if r["kind"] == "other"]
+    c_ms, c_fl, c_ex, c_n = (sum(r[k] for r in con) for k in ("ms", "gflop", "executed_gflop", "launches"))
+    all_n, all_ms = sum(r["launches"] for r in recs), sum(r["ms"] for r in recs)
+    raw_all = all_ms / psteps
+    scale = min(1.0, plain_ms / raw_all) if raw_all > 0 else 1.0
+    achieved = c_fl / (c_ms * scale) if c_ms > 0 else 0.0  # GFLOP / ms = TFLOP/s
+    executed = c_ex / (c_ms * scale) if c_ms > 0 else 0.0
+    per_rank = ctx.gather_objects(round(c_ms * scale / psteps, 4))
+    return {
+        "kernel": "all Conv1d / Linear contractions of the step (conv_gemm kernels, Winograd-form convs timed with their transforms, fused WaveNet-layer kernels)",
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "achieved_note": "algorithmic (direct-conv) flops / calibrated kernel time: SURVEY.md 8d; a Winograd-form conv is credited with the flops of the direct convolution it replaces",
+        "executed_tflops": round(executed, 2), "frac_executed": round(executed / peak, 4),
+        "executed_note": "flops the matrix cores actually execute (F(6,7)/F(6,3)/F(2,5)/F(4,5) forms do n/(m r) of the direct multiplies) / the same kernel time",
+        "event_calibration": {"plain_step_gpu_ms": round(plain_ms, 4), "sum_of_event_timed_kernels_ms": round(raw_all, 4), "scale": round(scale, 4),
+                              "frac_uncalibrated": round(c_fl / c_ms / peak, 4) if c_ms > 0 else 0.0,
+                              "note": "durations x scale: the instrumented pass (an event pair on every launch) cannot be shorter than the step it describes"},
+        "traffic": traffic, "traffic_note": traffic_note,
+        "launches_per_step": c_n // psteps, "avg_launch_ms": round(c_ms * scale / max(c_n, 1), 5),
+        "algorithmic_gflop_per_step": round(c_fl / psteps, 2), "executed_gflop_per_step": round(c_ex / psteps, 2),
+        "gemm_ms_per_step": round(c_ms * scale / psteps, 4), "gemm_ms_per_step_per_rank": per_rank,
+        "gemm_share_of_step": round((c_ms * scale / psteps) / ms_per_step, 4),
+        "contraction_kernels": [
+            {"kernel": r["kernel"], "launches_per_step": r["launches"] // psteps, "ms_per_step": round(r["ms"] * scale / psteps, 4),
+             "avg_us": round(1e3 * r["ms"] * scale / r["launches"], 2), "tflops": round(r["gflop"] / (r["ms"] * scale), 1),
+             "executed_tflops": round(r["executed_gflop"] / (r["ms"] * scale), 1)}
+            for r in con],
+        "hbm_kernels": [
+            {"kernel": r["kernel"], "launches_per_step": r["launches"] // psteps, "avg_us": round(1e3 * r["ms"] * scale / r["launches"], 2),
+             "algorithmic_mb_per_launch": round(r["mbytes"] / r["launches"], 3), "gb_per_s": round(r["mbytes"] / (r["ms"] * scale), 1),
+             "frac_of_8tb_s": round(r["mbytes"] / (r["ms"] * scale) / 8000.0, 4)}
+            for r in sorted(oth, key=lambda r: -r["ms"])],
+        "hbm_kernels_note": "bandwidth-/latency-bound kernels: algorithmic HBM bytes (SURVEY.md 8d: inputs read once + outputs written once) / calibrated duration, against 8 TB/s",
+        "all_launches_per_step": all_n // psteps, "all_kernel_ms_per_step": round(raw_all * scale, 4),
+        "us_per_launch": round(1e3 * raw_all * scale / max(all_n // psteps, 1), 2),
+    }
+
+
+# ------------------------------------------------------------------------------------------------ cfg4 / cfg5: one fixed global batch, sharded
+def run_sharded(ctx: Ctx, args, name: str, steps: int, warmup: int, n_utt: int = 0):
+    """ONE fixed global batch, utterances partitioned over the ranks by frame count (longest first), every rank runs its shard through
+    stts_frame_path (in calls of at most MAX_ROWS_PER_CALL frames) and the waveforms are collected on rank 0 with exact sizes
+    (sharding.WaveformCollector) inside the timed step.  Strong scaling: `value` = utterances of the global batch / step time."""
+    import numpy as np
+    import torch
+
+    from stylish_tts_amd.config import load_model_config
+    from stylish_tts_amd.runtime import HipModel, Segments
+    from stylish_tts_amd.sharding import WaveformCollector, partition_utterances
+
+    wl = WORKLOADS[name]
+    precision = wl["precision"] if args.precision == "f32" else args.precision
+    cfg = load_model_config()
+    w = broadcast_weights(ctx, ["speech_predictor"], cfg)
+    model = HipModel(cfg, ctx.local, precision=precision)
+    model.load_weights(w, which=7)
+    device = ctx.device
+    n_utt = n_utt or args.utterances or wl["n_utt"]
     rng = np.random.default_rng(4)
     secs = rng.uniform(wl["seconds"][0], wl["seconds"][1], n_utt)
     frames = [int(4 * max(1, round(80 * v))) for v in secs]  # vocoder frames per utterance (T4 = 4 T)
-    parts = partition_utterances(frames, world)
-    mine = parts[rank]
-    # this rank's calls: consecutive utterances of its shard, at most MAX_ROWS_PER_CALL frames each
-    calls, cur, rows = [], [], 0
+    parts = partition_utterances(frames, ctx.world)
+    mine = parts[ctx.rank]
+    calls, cur, rows = [], [], 0  # this rank's calls: consecutive utterances of its shard, at most MAX_ROWS_PER_CALL frames each
     for i in mine:
         if cur and rows + frames[i] > MAX_ROWS_PER_CALL:
             calls.append(cur)
@@ -162,64 +420,171 @@ def run_sharded(args, world, rank, local, device, dist):
     for ci, ids in enumerate(calls):
         L = [frames[i] for i in ids]
         R = sum(L)
-        seed = 1000 * rank + ci
+        seed = 1000 * ctx.rank + ci
         pitch = 80.0 + 220.0 * rand((R,), seed + 1, normal=False)
         pitch = torch.where(rand((R,), seed + 2, normal=False) < 0.3, torch.zeros_like(pitch), pitch)  # ~30 % unvoiced frames
         batches.append(dict(seg=Segments(L, device), asr=rand((R, 128), seed + 3), pitch=pitch, energy=2 + 2 * rand((R,), seed + 4, normal=False),
                             style=0.7 * rand((len(ids), 64), seed + 5), pn=rand((R, 128), seed + 6), sn=rand((R * 75,), seed + 7),
                             ph=rand((1,), seed + 8, normal=False), rows=R))
     my_rows = sum(b["rows"] for b in batches)
-    audio = torch.empty(my_rows * 75, dtype=torch.float32, device=device)
-    col = WaveformCollector([75 * f for f in frames], device, dst=0) if world > 1 else None
+    audio = torch.empty(max(my_rows, 1) * 75, dtype=torch.float32, device=device)[: my_rows * 75]
+    col = WaveformCollector([75 * f for f in frames], device, dst=0) if ctx.world > 1 else None
 
     def step():
         off = 0
         for b in batches:
             model.frame_path(b["seg"], b["asr"], b["pitch"], b["energy"], b["style"], b["pn"], b["sn"], b["ph"], batch_scope=False,
-                             out=audio[75 * off : 75 * (off + b["rows"])])
+                             out=audio[75 * off: 75 * (off + b["rows"])])
             off += b["rows"]
         if col is not None:
             col.collect(audio)
 
-    for _ in range(args.warmup):
-        step()
-    model.check_status()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    rows_all = [sum(frames[i] for i in p) for p in parts]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(ctx, step, steps, warmup, after_warmup=model.check_status)
     assert bool(torch.isfinite(audio).all())
-    if rank == 0:
-        audio_seconds = args.steps * sum(frames) * 75 / SR
-        print(json.dumps({
-            "metric": "utterances_per_sec", "value": round(args.steps * n_utt / elapsed, 3), "unit": "utt/s",
-            "rtf": elapsed / audio_seconds, "realtime_x": audio_seconds / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": precision,
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {wl['note']} ({sum(frames) * 75 / SR:.0f} s of audio per step), {precision} "
-                            "Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); one fixed global batch per step",
-                "global_batch": n_utt, "utterances_per_rank": [len(p) for p in parts], "frames_per_rank": rows_all,
-                "imbalance_max_over_mean": round(max(rows_all) / (sum(rows_all) / world), 4), "calls_per_rank_step": len(calls),
-                "parallelism": (f"utterance-sharded x{world} (longest-first greedy on frame counts); RCCL broadcast(weights, once) + exact-size "
-                                "point-to-point collection of the waveforms on rank 0 per step") if world > 1 else "single GPU",
-            },
-        }), flush=True)
+    rows_all = [sum(frames[i] for i in p) for p in parts]
+    audio_seconds = steps * sum(frames) * 75 / SR
+    out = {
+        "metric": "utterances_per_sec", "value": round(steps * n_utt / elapsed, 3), "unit": "utt/s",
+        "rtf": elapsed / audio_seconds, "realtime_x": audio_seconds / elapsed, "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": precision,
+        "data": "synthetic",
+        "frame_tflops": round(sum(frames) * steps * FRAME_MFLOP * 1e-6 / elapsed, 1),
+        "frac_of_mfma_peak": round(sum(frames) * steps * FRAME_MFLOP * 1e-6 / elapsed / (MFMA_PEAK_TFLOPS[precision] * ctx.world), 4),
+        "config": {
+            "workload": f"{name}: {wl['note']} ({sum(frames) * 75 / SR:.0f} s of audio per step), {precision} "
+                        "Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); one fixed global batch per step",
+            "global_batch": n_utt, "utterances_per_rank": [len(p) for p in parts], "frames_per_rank": rows_all,
+            "imbalance_max_over_mean": round(max(rows_all) / (sum(rows_all) / ctx.world), 4), "calls_per_rank_step": len(calls),
+            "ranks": ctx.world if ctx.world == 1 else ctx.dist.get_world_size(), "backend": ctx.backend or "none",
+            "collect_bytes_per_step": 0 if ctx.world == 1 else 4 * 75 * (sum(frames) - rows_all[0]),
+            "parallelism": (f"utterance-sharded x{ctx.world} (longest-first greedy on frame counts); {ctx.backend} broadcast(weights, once) + exact-size "
+                            "point-to-point collection of the waveforms on rank 0 per step") if ctx.world > 1 else "single GPU",
+        },
+    }
     model.close()
+    return out
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ cfg3: the full chain, tokens -> waveform
+def cfg3_weights(ctx: Ctx, cfg):
+    """Synthetic weights of the five inference modules; the duration head's bias is shaped so that the synthetic model predicts
+    LJSpeech-like durations (~5 mel frames per token: 50 tokens -> T ~ 240 = 3 s) instead of the ~15 frames per
+    token a near-uniform softmax over the 16-class table gives."""
+    import numpy as np
+
+    from stylish_tts_amd import params
+
+    w = broadcast_weights(ctx, list(params.MODULE_SPECS), cfg)
+    b = np.asarray(w["duration_predictor"]["duration_proj.linear_layer.bias"], np.float32).copy()
+    table = np.array([1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46], np.float32)
+    b += (-1.5 * np.abs(table - 4.8)).astype(np.float32)  # classes 4 / 5 / 6 frames win the argmax, token-dependent logits pick among them
+    w["duration_predictor"]["duration_proj.linear_layer.bias"] = b
+    return w
+
+
+def run_cfg3(ctx: Ctx, args, steps: int, warmup: int):
+    """BASELINE configs[2]: 64 utterances x 50 tokens per GPU through the whole chain (Synthesizer: duration predictor ->
+    DurationProcessor -> pitch/energy -> speech predictor), frame path with bf16 operands, phoneme-rate predictors in fp32.
+    "Style diffusion" does not exist in the reference: the stochastic prior + reverse flow is what runs.  Weak scaling."""
+    import torch
+
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.config import load_model_config
+    from stylish_tts_amd.pipeline import Synthesizer
+    from stylish_tts_amd.runtime import HipModel
+
+    precision = "bf16" if args.precision == "f32" else args.precision
+    B, P = args.cfg3_batch, args.cfg3_tokens
+    cfg = load_model_config()
+    w = cfg3_weights(ctx, cfg)
+    eng = HipModel(cfg, ctx.local, precision=precision)
+    eng.load_weights(w, which=255)
+    syn = Synthesizer(eng)
+    toks = [synth.tokens(f"bench.cfg3.r{ctx.rank}.{i}", 1, P, cfg.text_encoder.tokens)[0].tolist() for i in range(B)]
+    waves, det = syn(toks, return_details=True)
+    frames = det["frames"]  # mel frames per utterance
+    R4 = 4 * sum(frames)
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(77 + ctx.rank)
+    noise = dict(prior_noise=torch.randn(R4, 128, generator=gen, device=ctx.device), src_noise=torch.randn(R4 * 75, generator=gen, device=ctx.device),
+                 init_phase=torch.rand(1, generator=gen, device=ctx.device))
+    state = {}
+
+    def step():
+        state["waves"] = syn(toks, noise=noise)
+
+    elapsed = timed_steps(ctx, step, steps, warmup)
+    assert all(bool(torch.isfinite(x).all()) for x in state["waves"])
+    # stage split (one extra call, events on the caller's stream): phoneme-rate part = everything before the frame path
+    t = syn.stage_times(toks, noise)
+    utts = ctx.world * B * steps
+    audio_seconds = ctx.world * steps * sum(frames) * 300 / SR
+    ph_gflop = PHONEME_GFLOP_PER_TOKEN * P * B
+    fr_gflop = FRAME_MFLOP * 1e-3 * R4
+    out = {
+        "metric": "utterances_per_sec", "value": round(utts / elapsed, 3), "unit": "utt/s",
+        "rtf": elapsed / audio_seconds, "realtime_x": audio_seconds / elapsed, "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
+        "config": {
+            "workload": f"cfg3: LJSpeech-shaped batch={B} x {P} tokens per GPU, tokens -> waveform through the whole chain (duration predictor, DurationProcessor, pitch/energy "
+                        f"predictor in fp32; Decoder + prior/reverse flow + vocoder with {precision} matrix-core operands, fp32 accumulate); the reference has no style-diffusion "
+                        "step: the stochastic prior + reverse flow is what runs",
+            "batch_per_gpu": B, "tokens_per_utt": P, "mel_frames_per_utt_mean": round(sum(frames) / B, 1), "audio_seconds_per_utt_mean": round(sum(frames) * 300 / SR / B, 2),
+            "duration_bias_note": "duration_proj bias shaped so the synthetic model predicts ~5 frames per token (SURVEY.md 8d: P = 50 -> T = 240)",
+            "host_syncs_between_duration_and_frame_path": syn.host_syncs_per_call,
+        },
+        "roofline": {
+            "phoneme_rate": {"ms": round(t["phoneme_ms"], 3), "gflop": round(ph_gflop, 1), "tflops": round(ph_gflop / t["phoneme_ms"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "frac": round(ph_gflop / t["phoneme_ms"] / FP32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32",
+                             "note": "SURVEY.md 8d: ~3.6 GFLOP per 50-token utterance; latency-bound (hundreds of small launches)"},
+            "frame_rate": {"ms": round(t["frame_ms"], 3), "gflop": round(fr_gflop, 1), "tflops": round(fr_gflop / t["frame_ms"], 1), "peak": MFMA_PEAK_TFLOPS[precision],
+                           "frac": round(fr_gflop / t["frame_ms"] / MFMA_PEAK_TFLOPS[precision], 4), "dtype": precision,
+                           "note": "SURVEY.md 8d: 74.1 MFLOP per hop-75 frame, whole stts_frame_path (contractions + bandwidth-bound kernels) against the dense 16-bit MFMA peak"},
+            "stage_note": "one serialised call with events between the stages; in the timed steps the phoneme-rate side streams overlap",
+        },
+    }
+    eng.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 plumbing without a GPU (CPU test of the launcher)
+def plumbing_check(args, world, rank):
+    """tests/test_bench_launcher.py: the ranks started by the parent rendezvous over gloo on the CPU and run the sharded workload's
+    partition + exact-size collection on fabricated waveforms (utterance i filled with i).  No GPU, no compute, no metric."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from stylish_tts_amd.sharding import WaveformCollector, partition_utterances
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if args.fail_rank == rank:
+            raise SystemExit(3)
+        rng = np.random.default_rng(4)
+        frames = [int(4 * max(1, round(80 * v))) for v in rng.uniform(0.25, 2.0, 24)]
+        parts = partition_utterances(frames, world)
+        col = WaveformCollector([3 * f for f in frames], "cpu", dst=0)
+        local = torch.cat([torch.full((3 * frames[i],), float(i)) for i in parts[rank]]) if parts[rank] else torch.zeros(0)
+        col.collect(local)
+        ok = True
+        if rank == 0:
+            ok = all(bool((col.utterance(i) == float(i)).all()) and col.utterance(i).numel() == 3 * frames[i] for i in range(len(frames)))
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            rows = [sum(frames[i] for i in p) for p in parts]
+            print(json.dumps({"plumbing_check": True, "ok": bool(t.item() == 1.0), "metric": "utterances_per_sec", "value": None, "n_gpus": world,
+                              "ranks": dist.get_world_size(), "backend": "gloo", "frames_per_rank": rows,
+                              "imbalance_max_over_mean": round(max(rows) / (sum(rows) / world), 4)}), flush=True)
+        if t.item() != 1.0:
+            raise SystemExit(4)
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ main
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -228,232 +593,110 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step (BASELINE cfg2 = 8; other values are side experiments)")
     ap.add_argument("--mel-frames", type=int, default=240, help="mel frames per utterance (cfg2 = 240 = 3.0 s)")
     ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
-                    help="operand precision of the contractions; f32 = BASELINE cfg2 (the bench line), bf16 / f16 = cfg3 / cfg5 arithmetic (side experiments)")
-    ap.add_argument("--cpu-utts", type=int, default=16, help="utterances the CPU baseline times (bounded sample: ~10-20 s of host work)")
+                    help="operand precision of the frame-rate contractions; f32 = BASELINE cfg2 (the bench line); cfg3 / cfg5 default to bf16 / f16")
+    ap.add_argument("--cpu-utts", type=int, default=16, help="utterances the CPU baseline times (bounded sample: ~10-30 s of host work)")
+    ap.add_argument("--cpu-threads", type=int, default=2, help="BLAS threads per CPU-baseline worker process")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline worker processes (0: fill the one-GPU box's share of 16 cores)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-legs", action="store_true", help="only the bench line (no cfg3 / cfg4 / cfg5 legs)")
+    ap.add_argument("--legs", default="cfg4,cfg5,cfg3", help="comma-separated legs run after the bench line")
+    ap.add_argument("--leg-steps", type=int, default=5)
+    ap.add_argument("--leg-warmup", type=int, default=2)
+    ap.add_argument("--cfg3-batch", type=int, default=64)
+    ap.add_argument("--cfg3-tokens", type=int, default=50)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the counter passes run this script with the legs off
-    ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
-                    help="cfg2 (default, the bench line): 8 x 3 s per GPU, weak scaling; cfg4 / cfg5: BASELINE's sharded configs, one fixed global batch "
-                         "partitioned over the ranks (strong scaling)")
+    ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)  # CPU test of the N > 1 launcher + collection (no GPU, no metric)
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
+                    help="cfg2 (default, the bench line + legs): 8 x 3 s per GPU, weak scaling; cfg3: the full chain at 64 x 50 tokens per GPU; cfg4 / cfg5: BASELINE's "
+                         "sharded configs, one fixed global batch partitioned over the ranks (strong scaling)")
     ap.add_argument("--utterances", type=int, default=0, help="cfg4 / cfg5: override the global batch size (rehearsals on one GPU)")
-    args = ap.parse_args()
-    global BATCH, T_MEL, T4
-    BATCH, T_MEL = args.batch, args.mel_frames
-    T4 = 4 * T_MEL
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    import __graft_entry__ as entry
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.pmc_child:
+        # ---- the driver's plain `python bench.py --gpus N`: this process is the GPU-free parent of N ranks
+        from stylish_tts_amd.launcher import launch_ranks
+
+        if not args.plumbing_check:
+            entry.compile()  # hipcc here, once, before any rank exists (the ranks find a fresh library)
+        rc, _ = launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=float(os.environ.get("STTS_BENCH_TIMEOUT", "1500")))
+        sys.exit(rc)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    traffic, traffic_note = None, "not measured (--no-traffic / multi-GPU run)"
-    if world == 1 and not args.pmc_child and not args.no_traffic and args.workload == "cfg2":
-        # before anything here touches the GPU: the counter passes are child processes of a GPU-free parent
-        traffic, traffic_note = measure_traffic(["--batch", str(args.batch), "--mel-frames", str(args.mel_frames), "--precision", args.precision])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; run `python bench.py --gpus N` (it starts its own ranks) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if args.plumbing_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return plumbing_check(args, world, rank)
+
+    # ---- nothing below this line may compile: build first, while this process has not touched the GPU
+    if args.pmc_child:
+        if entry.is_stale():  # under rocprofv3 the profiler's library has already initialised the GPU: never start hipcc from here
+            raise SystemExit("bench.py --pmc-child: libstylish_hip.so is missing or older than its sources; the parent compiles, the counter passes never do")
+    else:
+        entry.compile()  # file-locked: with several ranks one compiles, the others wait
+    cpu = None
+    traffic, traffic_note = None, "not measured (--no-traffic / multi-GPU run / another workload)"
+    if world == 1 and not args.pmc_child and args.workload == "cfg2":
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(args, 4 * args.mel_frames)  # worker processes, before the GPU is touched
+            except Exception as e:  # noqa: BLE001
+                cpu = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if not args.no_traffic:
+            traffic, traffic_note = measure_traffic(["--batch", str(args.batch), "--mel-frames", str(args.mel_frames), "--precision", args.precision])
+
+    import torch
     import torch.distributed as dist
 
+    entry.load()
+    ctx = Ctx(world, rank, local)
     if os.environ.get("STTS_BENCH_ONE_GPU"):  # rehearsal of the N > 1 code path on a single-GPU box: every rank on cuda:0
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+        ctx.local = 0
+    torch.cuda.set_device(ctx.local)
+    ctx.device = torch.device("cuda", ctx.local)
+    ctx.dist = dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("STTS_BENCH_BACKEND", "nccl")  # "gloo": rehearsals without RCCL (one GPU shared by the ranks)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        ctx.backend = os.environ.get("STTS_BENCH_BACKEND", "nccl")  # "gloo": rehearsals without RCCL (one GPU shared by the ranks)
+        if ctx.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=ctx.device)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.workload != "cfg2":
-        run_sharded(args, world, rank, local, device, dist)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+            dist.init_process_group(ctx.backend, rank=rank, world_size=world)
 
-    import __graft_entry__ as entry
-
-    if rank == 0:
-        entry.build()
-    if world > 1:
-        dist.barrier()
-
-    from stylish_tts_amd import _lib, params
-    from stylish_tts_amd.config import load_model_config
-    from stylish_tts_amd.runtime import HipModel, Segments
-    from stylish_tts_amd.sharding import broadcast_state_dict
-
-    cfg = load_model_config()
-    spec = params.module_spec("speech_predictor", cfg)
-    sd = params.synth_state_dict(spec, 0, prefix="speech_predictor.") if rank == 0 else None
-    if world > 1:
-        sd = broadcast_state_dict(sd, spec, device, src=0)  # RCCL broadcast of the weights, once
-    model = HipModel(cfg, local, precision=args.precision)
-    model.load_weights({"speech_predictor": sd}, which=7)
-
-    seg = Segments([T4] * BATCH, device)
-    inp = synth_inputs(rank, device)
-    audio = torch.empty(BATCH * T4 * 75, dtype=torch.float32, device=device)
-    gathered = [torch.empty_like(audio) for _ in range(world)] if (world > 1 and rank == 0) else None
-
-    collect = {"mode": "gather"}
-    all_buf = torch.empty(world * audio.numel(), dtype=torch.float32, device=device) if world > 1 else None
-
-    def step():
-        model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
-                         batch_scope=True, out=audio)
-        if world > 1:
-            if collect["mode"] == "gather":
-                dist.gather(audio, gathered, dst=0)  # waveforms to rank 0 over xGMI
-            else:
-                dist.all_gather_into_tensor(all_buf, audio)
-
-    if world > 1:
-        # pick the collective once, outside the timed region: gather (rank 0 receives) unless this RCCL build lacks it
-        ok = torch.ones(1, device=device)
-        try:
-            dist.gather(audio, gathered, dst=0)
-            torch.cuda.synchronize()
-        except Exception as e:  # pragma: no cover
-            ok.zero_()
-            print(f"[bench] rank {rank}: dist.gather unavailable ({e}); using all_gather_into_tensor", file=sys.stderr)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() < 1:
-            collect["mode"] = "all_gather"
-
-    for _ in range(args.warmup):
-        step()
-    model.check_status()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(audio).all()
-
-    utts = world * BATCH * args.steps
-    value = utts / elapsed
-    audio_seconds = utts * (T4 * 75 / SR)
-    out = {
-        "metric": "utterances_per_sec",
-        "value": round(value, 3),
-        "unit": "utt/s",
-        "rtf": elapsed / audio_seconds,
-        "realtime_x": audio_seconds / elapsed,
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": args.precision,
-        "data": "synthetic",
-        "config": {
-            "workload": ("cfg2: " if (BATCH, T_MEL, args.precision) == (8, 240, "f32") else "side experiment: ") + f"LJSpeech-shaped batch={BATCH} x {T_MEL / 80:.1f} s (T={T_MEL} mel frames, {T4 * 75} samples @24 kHz) " + ("fp32" if args.precision == "f32" else f"{args.precision} matrix-core operands, fp32 accumulate") + ", "
-                        "Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); no diffusion step exists in the reference",
-            "batch_per_gpu": BATCH,
-            "global_batch": BATCH * world,
-            "frames_per_utt": T4,
-            "parallelism": f"utterance-sharded x{world}; RCCL broadcast(weights, once) + gather(waveforms, per step)" if world > 1 else "single GPU",
-        },
-    }
-
-    if rank == 0 and not args.pmc_child:
-        # ---- roofline leg: HIP events around every launch of the step (same stream), 3 steps right after the timed region
-        # (rank 0's own frame path, without the collection of the waveforms: the other ranks wait at the barrier below)
-        lib = _lib.load()
-        psteps = 3
-        lib.stts_profile_begin()
-        for _ in range(psteps):
-            model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
-                             batch_scope=True, out=audio)
-        buf = C.create_string_buffer(1 << 16)
-        _lib.check(lib.stts_profile_report(C.c_void_p(torch.cuda.current_stream().cuda_stream), buf, len(buf)))
-        recs = json.loads(buf.value.decode())
-        peak = MFMA_PEAK_TFLOPS[args.precision]
-        con = [r for r in recs if r["kind"] == "contraction"]
-        oth = [r for r in recs if r["kind"] == "other"]
-        c_ms, c_fl, c_ex, c_n = (sum(r[k] for r in con) for k in ("ms", "gflop", "executed_gflop", "launches"))
-        achieved = c_fl / c_ms if c_ms > 0 else 0.0        # GFLOP / ms = TFLOP/s
-        executed = c_ex / c_ms if c_ms > 0 else 0.0
-        all_n, all_ms = sum(r["launches"] for r in recs), sum(r["ms"] for r in recs)
-        out["roofline"] = {
-            "kernel": "conv_gemm_f32 + Winograd-form convs (timed with their transforms) + fused WaveNet-layer kernel = all Conv1d/Linear contractions of the step",
-            "bound": "mfma",
-            "achieved": round(achieved, 2),
-            "peak": peak,
-            "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4),
-            "achieved_note": "algorithmic (direct-conv) flops / kernel time: SURVEY.md 8d; a Winograd-form conv is credited with the flops of the direct convolution it replaces",
-            "executed_tflops": round(executed, 2),
-            "frac_executed": round(executed / peak, 4),
-            "executed_note": "flops the matrix cores actually execute (F(6,7)/F(6,3)/F(2,5)/F(4,5) forms do n/(m r) of the direct multiplies) / the same kernel time",
-            "traffic": traffic,
-            "traffic_note": traffic_note,
-            "launches_per_step": c_n // psteps,
-            "avg_launch_ms": round(c_ms / max(c_n, 1), 5),
-            "algorithmic_gflop_per_step": round(c_fl / psteps, 2),
-            "executed_gflop_per_step": round(c_ex / psteps, 2),
-            "gemm_ms_per_step": round(c_ms / psteps, 4),
-            "gemm_share_of_step": round((c_ms / psteps) / (1e3 * elapsed / args.steps), 4),
-            "contraction_kernels": [
-                {"kernel": r["kernel"], "launches_per_step": r["launches"] // psteps, "ms_per_step": round(r["ms"] / psteps, 4),
-                 "avg_us": round(1e3 * r["ms"] / r["launches"], 2), "tflops": round(r["gflop"] / r["ms"], 1), "executed_tflops": round(r["executed_gflop"] / r["ms"], 1)}
-                for r in con],
-            "hbm_kernels": [
-                {"kernel": r["kernel"], "launches_per_step": r["launches"] // psteps, "avg_us": round(1e3 * r["ms"] / r["launches"], 2),
-                 "algorithmic_mb_per_launch": round(r["mbytes"] / r["launches"], 3), "gb_per_s": round(r["mbytes"] / r["ms"], 1),
-                 "frac_of_8tb_s": round(r["mbytes"] / r["ms"] / 8000.0, 4)}
-                for r in sorted(oth, key=lambda r: -r["ms"])],
-            "hbm_kernels_note": "bandwidth-/latency-bound kernels: algorithmic HBM bytes (SURVEY.md 8d: inputs read once + outputs written once) / event-timed duration, against 8 TB/s",
-            "all_launches_per_step": all_n // psteps,
-            "all_kernel_ms_per_step": round(all_ms / psteps, 4),
-            "us_per_launch": round(1e3 * all_ms / max(all_n, 1), 2),
-        }
-        # ---- CPU baseline leg: the oracle (validated against reference goldens) on the host cores (N = 1 only)
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import stylish_oracle as O
-
-            h = inp["host"]
-            per_call = min(BATCH, max(1, args.cpu_utts))  # the workload's own batch per oracle call: BLAS sees the same matrix shapes the GPU step does
-            calls = max(1, args.cpu_utts // per_call)
-            n_utts = calls * per_call
-            asr_b = np.ascontiguousarray(h["asr"][: per_call * T4].reshape(per_call, T4, -1).transpose(0, 2, 1))
-            pitch_b, energy_b = h["pitch"][: per_call * T4].reshape(per_call, T4), h["energy"][: per_call * T4].reshape(per_call, T4)
-            nzb = dict(prior_noise=h["nz"]["prior_noise"][:per_call], src_noise=h["nz"]["src_noise"][:per_call], init_phase=h["nz"]["init_phase"])
-            t1 = time.perf_counter()
-            for _ in range(calls):
-                O.frame_path(asr_b, pitch_b, energy_b, h["style"][:per_call], nzb, sd)
-            cpu_t = time.perf_counter() - t1
-            try:  # the threads the oracle's matrix products actually ran on
-                from threadpoolctl import threadpool_info
-
-                blas_threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-            except Exception:
-                blas_threads = os.cpu_count()
-            out["cpu_baseline"] = {
-                "value": round(n_utts / cpu_t, 4),
-                "unit": "utt/s",
-                "cores": blas_threads,
-                "kind": "port",
-                "sample": f"{n_utts} utterances of the same workload (3.0 s each, {per_call} per oracle call like the GPU step, {calls} calls), numpy oracle; BLAS pool = {blas_threads} threads "
-                          f"of {os.cpu_count()} logical cores",
-                "reference_torch_cpu_note": "survey container, 8 vCPU, reference torch-CPU code: 1.4 utt/s at B=1, 1.9-2.5 utt/s at B=8 (BASELINE.md §2)",
-            }
+    if args.workload == "cfg2":
+        out = run_cfg2(ctx, args, traffic, traffic_note)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if not args.no_legs and not args.pmc_child and (args.batch, args.mel_frames, args.precision) == (8, 240, "f32"):
+            legs = {}
+            for leg in [x for x in args.legs.split(",") if x]:
+                t0 = time.perf_counter()
+                try:
+                    if leg in ("cfg4", "cfg5"):
+                        legs[leg + "_strong"] = run_sharded(ctx, args, leg, args.leg_steps, args.leg_warmup)
+                    elif leg == "cfg3":
+                        legs["cfg3_full_chain"] = run_cfg3(ctx, args, args.leg_steps, args.leg_warmup)
+                except Exception as e:  # noqa: BLE001 - a leg never takes the bench line down; all ranks fail alike (same inputs, same code)
+                    legs[leg] = {"error": f"{type(e).__name__}: {e}"}
+                if rank == 0:
+                    print(f"[bench] leg {leg}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+            out["legs"] = legs
+    elif args.workload == "cfg3":
+        out = run_cfg3(ctx, args, args.steps, args.warmup)
+    else:
+        out = run_sharded(ctx, args, args.workload, args.steps, args.warmup)
     if rank == 0 and not args.pmc_child:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()  # rank 0's roofline leg is over
-    model.close()
+    ctx.barrier()
     if world > 1:
         dist.destroy_process_group()
 

@@ -66,10 +66,14 @@ enum {
   STTS_W_CFM = 256           /* cfm_mel_decoder.* (finalized by stts_cfm_finalize, not part of STTS_W_ALL)  models/cfm/cfm_mel_decoder.py */
 };
 int stts_finalize_weights(stts_ctx* ctx, int which);
-/* Operand precision of the Conv1d / Linear contractions (call before the first stts_finalize_weights).
- * F32 is the reference's arithmetic (BASELINE cfg2).  BF16 / F16: activations stay fp32 in HBM and are rounded
- * to nearest-even when a tile is staged for the matrix cores, weights are stored pre-rounded, products
- * accumulate in fp32 (BASELINE cfg3 / cfg5); norms, gates, FFTs and every non-contraction kernel stay fp32. */
+/* Operand precision of the FRAME-RATE Conv1d / Linear contractions (call before the first stts_finalize_weights).
+ * F32 is the reference's arithmetic (BASELINE cfg2).  BF16 / F16 (BASELINE cfg3 / cfg5): the operands of every matrix-core
+ * contraction of the decoder, the flow and the vocoder are rounded to nearest-even exactly once - weights when they are packed,
+ * activations either when a tile is staged for the matrix cores (calls of < 3 840 rows: they stay fp32 in HBM) or by the kernel
+ * that produces them (larger calls: contraction inputs are 16-bit rows in HBM; the same arithmetic) - and products accumulate
+ * in fp32; norms, gates, style projections, FFTs and every non-contraction kernel stay fp32.
+ * The PHONEME-RATE predictors (text encoders, style encoders, duration and pitch / energy predictors) always run in fp32:
+ * durations are integers (bit-exact against the fp32 reference in every mode) and those stages are latency-bound. */
 enum { STTS_PREC_F32 = 0, STTS_PREC_BF16 = 1, STTS_PREC_F16 = 2 };
 int stts_set_precision(stts_ctx* ctx, int precision);
 /* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz
@@ -97,7 +101,16 @@ int stts_prior_flow_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_
  * pitch [rows], src_noise [75*rows] ~ N(0,1), init_phase: device pointer to ONE float in [0,1) shared by the call.
  * batch_scope != 0: harmonic count from the min f0 of the whole call (reference semantics of a batched call);
  * 0: per utterance (the reference called per utterance).  Outputs har_spec / har_phase [rows, ld>=1025],
- * optional prior_signal [75*rows]. */
+ * optional prior_signal [75*rows].
+ * PARITY NOTE (conditional): har_phase = atan2(Im, Re) is discontinuous and feeds phase_prior_conv linearly
+ * (models/generator.py:408-413).  With center=True reflect padding frame 0 is even-symmetric, so its spectrum is real up to FFT
+ * rounding and every negative-real bin is +pi or -pi by the sign of rounding noise - in torch.stft too; ~0-magnitude bins have
+ * arbitrary phase.  This entry computes the transform in fp64 (the signs of the exact transform); it does NOT reproduce torch's
+ * coin flips.  Consequence: waveforms match the reference within 1e-3 everywhere only after the reference's value is adopted at
+ * those ill-conditioned bins (~0.09 % of the bins; tests do so through oracle.align_branch, which accepts a bin only if the two
+ * angles agree mod 2 pi within 5e-3 or the magnitude is < 2e-4).  Un-adopted (what stts_frame_path computes) the first ~40 frames of
+ * an utterance can differ from a given torch run by up to ~0.2, the rest by <= 1.5e-2; tests/test_hip_benchmarked_path.py pins
+ * that every such difference lies inside the receptive field of an adopted bin. */
 int stts_harmonic_stft(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
                        const float* pitch, const float* src_noise, const float* init_phase, int batch_scope,
                        float* prior_signal_out, float* har_spec, float* har_phase, int ld_har, void* ws, size_t ws_bytes);
@@ -212,7 +225,15 @@ int stts_profile_end(void* stream, int* launches, double* total_ms, double* tota
  * since stts_profile_begin.  Ends the measurement like stts_profile_end. */
 int stts_profile_report(void* stream, char* json, size_t json_capacity);
 
-/* Single operators, exposed for parity tests (same kernels the stages use). */
+/* AdaptiveGeneratorBlock.forward (HiFi-GAN MRF + Snake, models/ada_norm.py:109-120); standalone block only: the enclosing
+ * UpsampleGenerator cannot be instantiated in the reference. */
+int stts_op_mrf_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host,
+                      const int32_t* seg_off_dev, const float* x, int ldx, int channels, int kernel, const float* style, float* y,
+                      int ldy, void* ws, size_t ws_bytes);
+
+#ifdef STTS_TEST_OPS
+/* Test surface, only in a library built with -DSTTS_TEST_OPS (tests/ and tools/; not part of the product ABI).
+ * Single operators for parity tests (the same kernels the stages use): */
 /* F.conv1d(stride 1, zero pad (k-1)/2*dil) on time-major rows; w is the reference layout [cout, cin, k] on the HOST. */
 int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* x, int ldx, int cin,
                    const float* w_host, const float* bias_host, int cout, int k, int dil, int act, float* y, int ldy, int force_tile, int precision);
@@ -220,15 +241,11 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
 int stts_op_adain_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host,
                         const int32_t* seg_off_dev, const float* x, int ldx, int cin, int cout, const float* style, float* y, int ldy,
                         void* ws, size_t ws_bytes);
-/* AdaptiveGeneratorBlock.forward (HiFi-GAN MRF + Snake, models/ada_norm.py:109-120); standalone block only. */
-int stts_op_mrf_block(stts_ctx* ctx, void* stream, const char* prefix, int n_utt, const int32_t* seg_off_host,
-                      const int32_t* seg_off_dev, const float* x, int ldx, int channels, int kernel, const float* style, float* y,
-                      int ldy, void* ws, size_t ws_bytes);
-
 /* Tuning aid (tools/gemm_bench.py): average time of `iters` back-to-back contraction launches on synthetic data.
  * tile: 0 = the launcher's own choice; tune bits: 128 bf16 operands, 256 fp16 operands; only in a library built with
  * -DSTTS_GEMM_TRACE: 2/4/8/16 K-loop ablations (results invalid, timing only), 64 block-timeline trace. */
 int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int cin, int cout, int k, int tile, int iters, double* avg_ms, int tune);
+#endif /* STTS_TEST_OPS */
 
 #ifdef __cplusplus
 }

@@ -86,10 +86,13 @@ SIGNATURES = {
     "stts_profile_begin": (_I, []),
     "stts_profile_end": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "stts_profile_report": (_I, [_P, C.c_char_p, _SZ]),
+    "stts_op_mrf_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),
+}
+# the test surface (include/stylish_hip.h under STTS_TEST_OPS): present only in a library built with -DSTTS_TEST_OPS
+TEST_SIGNATURES = {
     "stts_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _I]),
     "stts_op_conv1d": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I]),
     "stts_op_adain_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),
-    "stts_op_mrf_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),
 }
 
 _lib = None
@@ -118,6 +121,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in TEST_SIGNATURES.items():  # a product-only build (STTS_PRODUCT_ONLY=1) has none of these
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

@@ -71,18 +71,33 @@ int stts_load_weight(stts_ctx* c, const char* name, const float* data, const int
   API_END
 }
 
+// every exit path of a finalize leaves the allocation tag at "context lifetime"
+struct TagReset {
+  stts_ctx* c;
+  ~TagReset() { c->cur_tag = 0; }
+};
+
 int stts_finalize_weights(stts_ctx* c, int which) {
   API_BEGIN
   STTS_CHECK(c, "null ctx");
   STTS_HIP(hipSetDevice(c->device));
-  free_component_allocs(c, which);  // re-finalizing: the previous packing of these components goes away
+  TagReset tag_reset{c};
+  // re-finalizing: the previous packing of these components goes away, and so do their `ready` bits - they come back only for
+  // the components that finalize successfully below (a failed re-finalize must not leave a stage runnable on freed buffers)
+  c->ready &= ~which;
+  free_component_allocs(c, which);
   if (which & (STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR)) STTS_TRY(finalize_frame(c, which));
   const int ph = which & (STTS_W_SPEECH_TEXT | STTS_W_DURATION | STTS_W_PE_TEXT | STTS_W_PE_STYLE | STTS_W_PITCH_ENERGY);
   if (ph) {
     if (!c->phoneme) c->phoneme = std::make_shared<PhonemeModel>();
-    STTS_TRY(finalize_phoneme(c, static_cast<PhonemeModel*>(c->phoneme.get()), ph));
+    // the phoneme-rate predictors always run in fp32 (include/stylish_hip.h, stts_set_precision): durations are integers and must
+    // equal the fp32 reference's bit for bit, and these stages are latency-bound (nothing to win from 16-bit operands)
+    const int saved_prec = c->prec;
+    c->prec = PREC_F32;
+    const int rc = finalize_phoneme(c, static_cast<PhonemeModel*>(c->phoneme.get()), ph);
+    c->prec = saved_prec;
+    STTS_TRY(rc);
     c->ready |= ph;
-    c->cur_tag = 0;
   }
   STTS_HIP(hipDeviceSynchronize());
   return 0;
@@ -210,8 +225,9 @@ int stts_cfm_finalize(stts_ctx* c, const stts_cfm_dims* dims) {
   API_BEGIN
   STTS_CHECK(c && dims, "null argument");
   STTS_HIP(hipSetDevice(c->device));
-  free_component_allocs(c, STTS_W_CFM);
+  TagReset tag_reset{c};
   c->ready &= ~STTS_W_CFM;
+  free_component_allocs(c, STTS_W_CFM);
   CfmDims d;
   d.feat = dims->feat_dim; d.asr = dims->asr_dim; d.spk = dims->spk_dim; d.hidden = dims->hidden_dim; d.emb = dims->emb_dim; d.depth = dims->depth;
   d.enc_blocks = dims->enc_blocks; d.dec_blocks = dims->dec_blocks; d.prev_depth = dims->prev_depth; d.post_depth = dims->post_depth; d.head_dim = dims->head_dim;
@@ -364,6 +380,7 @@ int stts_duration_to_alignment(void* stream, const int32_t* dur, int n_tokens, i
 static int conv_stft_tables(stts_ctx* c) {
   if (c->hann) return 0;
   STTS_HIP(hipSetDevice(c->device));
+  c->cur_tag = 0;  // context-lifetime tables, whatever was finalized last
   std::vector<float> h(kWin);
   for (int i = 0; i < kWin; ++i) h[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / kWin));
   STTS_TRY(dev_upload(c, h, &c->hann));
@@ -489,8 +506,9 @@ int stts_profile_report(void* stream, char* json, size_t cap) {
   API_END
 }
 
-// (test operators and the contraction micro-benchmark: test_ops.hip.h, same extern "C" surface)
-
 }  // extern "C"
 
+#include "mrf_block.hip.h"
+#ifdef STTS_TEST_OPS  // single-layer test operators + the contraction micro-benchmark (not part of the product surface)
 #include "test_ops.hip.h"
+#endif

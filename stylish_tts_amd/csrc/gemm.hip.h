@@ -870,27 +870,30 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 
 // grow-only scratch for split-K partial sums, one buffer per (device, launch stream): contractions issued on different
 // streams may run concurrently and must not share partials, and the null stream exists on every device.
-// Growing allocates a NEW buffer and retires the old one (freed when the process ends its use of the library, never while
-// kernels that were given it may still be queued), so a larger batch after small ones costs one hipMalloc, not a
-// device-wide synchronisation.
+// Growing allocates a NEW buffer and retires the old one (freed later, never while kernels that were given it may still be
+// queued), so a larger batch after small ones costs one hipMalloc, not a device-wide synchronisation.  Retired buffers are kept
+// PER DEVICE and reclaimed only from a call on that device, after synchronising it.
+// Stream capture: growth (hipMalloc, possibly hipDeviceSynchronize) is illegal inside a capture; callers that capture a stage into
+// a HIP graph run it once eagerly first (cfm_decoder.py does), which sizes this scratch, and shapes must not grow afterwards.
 inline float* splitk_scratch(hipStream_t st, size_t bytes) {
   struct Buf {
     float* p = nullptr;
     size_t cap = 0;
   };
   static std::map<std::pair<int, hipStream_t>, Buf> bufs;
-  static std::vector<void*> retired;
+  static std::map<int, std::vector<void*>> retired;  // per device
   static std::mutex mu;
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
   Buf& b = bufs[{dev, st}];
   if (bytes > b.cap) {
-    if (b.p) retired.push_back(b.p);
-    if (retired.size() > 8) {  // bounded: reclaim the oldest once everything queued so far has drained
+    std::vector<void*>& old = retired[dev];
+    if (b.p) old.push_back(b.p);
+    if (old.size() > 8) {  // bounded: reclaim this device's retired buffers once everything queued on it so far has drained
       (void)hipDeviceSynchronize();
-      for (void* q : retired) (void)hipFree(q);
-      retired.clear();
+      for (void* q : old) (void)hipFree(q);
+      old.clear();
     }
     b.cap = std::max(bytes + bytes / 2, (size_t)(8u << 20));
     if (hipMalloc(&b.p, b.cap) != hipSuccess) {

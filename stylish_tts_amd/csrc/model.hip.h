@@ -975,13 +975,16 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   const long R = s.rows();
   const int ccat = d.dec_hidden + d.dec_residual + 2, ldcat = round_up(ccat, 32);  // 578 -> 608
   const int cenc = d.inter_dim + 2, ldenc = round_up(cenc, 32);                    // 130 -> 160
+  // (dec[0] runs on the encoder-input width, the other blocks on the concat width: scratch is sized by the wider of the two - a config
+  //  with inter_dim > hidden_dim + residual_dim is legal)
+  const int ldwide = std::max(ldenc, ldcat);
   float* enc_in = ws.get<float>(R * ldenc);
   float* xa = ws.get<float>(R * ldcat);
   float* xb = ws.get<float>(R * ldcat);
-  float* act1 = ws.get<float>(R * ldcat);
+  float* act1 = ws.get<float>(R * ldwide);
   float* hbuf = ws.get<float>(R * d.dec_hidden);
   float* act2 = ws.get<float>(R * d.dec_hidden);
-  float* ss = ws.get<float>(adain_part_floats(s, ldcat));
+  float* ss = ws.get<float>(adain_part_floats(s, ldwide));
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
@@ -989,8 +992,8 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   // 16-bit modes, large batches: rounded copies of the blocks' inputs for the learned shortcuts, ping-pong like xa / xb: a block's
   // conv2 epilogue writes the hidden columns of the next block's copy, the constant columns (asr_res, F0, N) are rounded once
   const bool x16 = R >= rows16_threshold() && c->prec != PREC_F32 && d.dec_hidden % 8 == 0;
-  unsigned short* xs16a = x16 ? ws.get<unsigned short>(R * ldcat) : nullptr;
-  unsigned short* xs16b = x16 ? ws.get<unsigned short>(R * ldcat) : nullptr;
+  unsigned short* xs16a = x16 ? ws.get<unsigned short>(R * ldwide) : nullptr;
+  unsigned short* xs16b = x16 ? ws.get<unsigned short>(R * ldwide) : nullptr;
   STTS_CHECK(ws.ok, "decoder_forward: workspace too small");
   STTS_DRY_RETURN(ws);
   STTS_TRY(run_style(st, c->dec_style, style, s.n_utt, sty));

@@ -88,6 +88,20 @@ class Synthesizer:
     def __call__(self, token_lists: Sequence[Sequence[int]], noise: Optional[Dict[str, torch.Tensor]] = None, return_details: bool = False):
         return self._run(token_lists, noise, return_details, self._lane)
 
+    host_syncs_per_call = 1  # reads of device data by the host between the duration predictor and the frame path
+
+    def stage_times(self, token_lists, noise=None) -> Dict[str, float]:
+        """One call with events between the stages on the caller's stream: milliseconds of the phoneme-rate part (everything up to
+        the frame path's inputs: three text encoders, styles, durations, pitch / energy, length regulator) and of the frame path."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        self._events = ev
+        try:
+            self._run(token_lists, noise, False, self._lane)
+        finally:
+            self._events = None
+        torch.cuda.synchronize(self.eng.device)
+        return dict(phoneme_ms=ev[0].elapsed_time(ev[1]), frame_ms=ev[1].elapsed_time(ev[2]))
+
     @torch.no_grad()
     def _run(self, token_lists, noise, return_details, lane):
         eng, dev = self.eng, self.eng.device
@@ -95,6 +109,9 @@ class Synthesizer:
         toks = torch.tensor([int(v) for t in token_lists for v in t], dtype=torch.int64, device=dev)
         sp = Segments(L, dev)
         main = torch.cuda.current_stream(dev)
+        ev = getattr(self, "_events", None)
+        if ev:
+            ev[0].record(main)
         ready = torch.cuda.Event()
         ready.record(main)
         # 2a/3a. the pitch/energy and speech text + style encoders: phoneme-rate, independent of the durations
@@ -130,7 +147,11 @@ class Synthesizer:
         if noise is None:
             noise = dict(prior_noise=torch.randn(R, 128, device=dev), src_noise=torch.randn(R * 75, device=dev),
                          init_phase=torch.rand(1, device=dev))
+        if ev:
+            ev[1].record(main)
         audio = eng.frame_path(st4, asr, p4, e4, style, noise["prior_noise"], noise["src_noise"], noise["init_phase"], batch_scope=False)
+        if ev:
+            ev[2].record(main)
         eng.check_status()
         waves = [audio[75 * int(st4.host[i]) : 75 * int(st4.host[i + 1])] for i in range(len(L))]
         if return_details:

@@ -79,10 +79,13 @@ class WaveformCollector:
     transfer per peer (``batch_isend_irecv``: over RCCL the peers write to `dst` over separate xGMI links; no ring, no
     padding to the largest shard).  ``utterance(i)`` returns a view into the receive buffer."""
 
-    def __init__(self, sample_counts: Sequence[int], device, dst: int = 0):
+    def __init__(self, sample_counts: Sequence[int], device, dst: int = 0, parts: Optional[Sequence[Sequence[int]]] = None):
+        """parts: the utterance ids of every rank (ascending), when the caller already has a partition (e.g. rank r owns a fixed
+        block of the global batch); default: the deterministic longest-first partition of `sample_counts`."""
         self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
         self.counts = [int(c) for c in sample_counts]
-        self.parts = partition_utterances(self.counts, self.world)
+        self.parts = [sorted(int(i) for i in p) for p in parts] if parts is not None else partition_utterances(self.counts, self.world)
+        assert len(self.parts) == self.world and sorted(i for p in self.parts for i in p) == list(range(len(self.counts))), "parts must cover every utterance once"
         self.sizes = [int(sum(self.counts[i] for i in p)) for p in self.parts]
         self.offsets = [0]
         for n in self.sizes:

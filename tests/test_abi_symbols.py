@@ -15,7 +15,11 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 20
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in stylish_hip.h but not exported"
-    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    bound = set(_lib.SIGNATURES) | set(_lib.TEST_SIGNATURES)
+    assert declared == bound, declared ^ bound
+    # the test surface sits behind STTS_TEST_OPS in the header, and only there
+    test_part = re.search(r"#ifdef STTS_TEST_OPS(.*?)#endif", hdr, flags=re.S).group(1)
+    assert set(re.findall(r"\b(stts_[a-z0-9_]+)\s*\(", test_part)) == set(_lib.TEST_SIGNATURES)
     assert lib.stts_version() >= 1
 
 

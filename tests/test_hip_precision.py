@@ -171,14 +171,11 @@ def test_frame_path_16bit_ragged_batch(cfg, weights, rounded_oracle, prec):
         assert ef < TOL[prec][1], (prec, errs)
 
 
-# phoneme-rate stages in the 16-bit modes, each fed the fp32 engine's inputs (teacher forcing: predicted durations decide
-# the frame count, so the chain is compared stage by stage).  Tolerances relative to each tensor's max-abs.
-# (measured: bf16 text 1.4e-2, style 2.5e-3, logits 1.1e-2, f0 1.7e-2, energy 3.9e-2; f16 2.4e-3, 3.0e-4, 1.2e-3, 2.6e-3, 5.3e-3)
-STAGE_TOL = {"bf16": dict(text=4e-2, style=1e-2, logits=3e-2, f0=5e-2, energy=1e-1), "f16": dict(text=6e-3, style=1e-3, logits=4e-3, f0=8e-3, energy=1.5e-2)}
-
-
+# The phoneme-rate predictors ALWAYS run in fp32 (include/stylish_hip.h, stts_set_precision): durations are integers (bar: bit-exact)
+# and these stages are latency-bound, so the 16-bit operand modes must leave them untouched - every tensor bit-identical to the
+# fp32 engine's, on a ragged batch.
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
-def test_phoneme_stages_16bit_vs_fp32(cfg, weights, prec):
+def test_phoneme_stages_stay_fp32_in_16bit_modes(cfg, weights, prec):
     from stylish_tts_amd import synth
     from stylish_tts_amd.runtime import HipModel
 
@@ -189,31 +186,25 @@ def test_phoneme_stages_16bit_vs_fp32(cfg, weights, prec):
     L = [23, 9, 41]
     toks = dev(np.concatenate([synth.tokens(f"h.{i}", 1, n, 178)[0] for i, n in enumerate(L)]).astype(np.int64))
     sp = segs(L)
-    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
-    got = {}
-    enc32, enc16 = e32.text_encoder(1, sp, toks), e16.text_encoder(1, sp, toks)
-    got["text"] = rel(enc16, enc32)
-    got["style"] = rel(e16.text_style(1, sp, enc32), e32.text_style(1, sp, enc32))
+    for which in (1, 2):
+        enc32, enc16 = e32.text_encoder(which, sp, toks), e16.text_encoder(which, sp, toks)
+        assert torch.equal(enc16, enc32), f"text encoder {which}"
+        assert torch.equal(e16.text_style(which, sp, enc32), e32.text_style(which, sp, enc32)), f"style encoder {which}"
     lg32, dur32 = e32.duration(sp, toks)
     lg16, dur16 = e16.duration(sp, toks)
-    got["logits"] = rel(lg16, lg32)
-    # durations are a rounded sum over 16 classes: the totals may move by a frame or two per utterance, not more
-    csum32, csum16 = torch.cumsum(dur32, 0).cpu().numpy(), torch.cumsum(dur16, 0).cpu().numpy()
-    ends = sp.host[1:] - 1
-    tot32, tot16 = np.diff(csum32[ends], prepend=0), np.diff(csum16[ends], prepend=0)
-    assert np.abs(tot32 - tot16).max() <= max(3, 0.03 * tot32.max()), (tot32, tot16)
-    T = [int(v) for v in tot32]
+    assert torch.equal(lg16, lg32) and torch.equal(dur16, dur32)
+    csum = torch.cumsum(dur32, 0).cpu().numpy()
+    T = [int(v) for v in np.diff(csum[sp.host[1:] - 1], prepend=0)]
     st = segs(T)
     pe32 = e32.text_encoder(2, sp, toks)
     ps32 = e32.text_style(2, sp, pe32)
     f32_, n32 = e32.pitch_energy(sp, st, dur32, pe32, ps32)
     f16_, n16 = e16.pitch_energy(sp, st, dur32, pe32, ps32)
-    got["f0"], got["energy"] = rel(f16_, f32_), rel(n16, n32)
-    print(prec, {k: f"{v:.2e}" for k, v in got.items()})
+    assert torch.equal(f16_, f32_) and torch.equal(n16, n32)
+    e32.check_status()
+    e16.check_status()
     e32.close()
     e16.close()
-    for k, v in got.items():
-        assert v < STAGE_TOL[prec][k], (prec, k, v)
 
 
 @pytest.mark.parametrize("prec,tol", [("bf16", 2e-2), ("f16", 3e-3)])
