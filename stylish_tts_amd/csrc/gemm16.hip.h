@@ -1,0 +1,365 @@
+// conv_gemm16_kernel: the dense contraction of the hot path for the 16-bit operand modes at large batches
+// (BASELINE cfg3 bf16 / cfg5 fp16): Conv1d k = 1..7 and Linear on v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate.
+//
+// Same contract as conv_gemm_f32<..., EPI_STORE, X16> (gemm.hip.h): activations are 16-bit TIME-MAJOR rows written by their
+// producers, weights are packed [cout][tap][cin] 16-bit, up to 3 K segments, utterance boundaries are the conv's zero padding,
+// epilogue = bias / activation / residual / alpha / fp32 and-or 16-bit store / GRN sums of squares.  What differs is the loop:
+//
+//   * block = 256 time rows x 256 output channels, K tile = 64 channels of one (segment, tap): 64 KB per stage, two stages;
+//   * every operand byte goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write), in half tiles of
+//     128 rows x 128 bytes; the 16-byte-slot swizzle slot ^= (row >> 1) & 7 is applied to the SOURCE slot a lane fetches (the LDS
+//     destination of an LDS-DMA is lane-linear), and to the fragment reads (conflict-free ds_read_b128);
+//   * 8 waves = 2 (time) x 4 (cout), wave tile 128 x 64 as 8 x 4 accumulators of 16 x 16; a K tile is FOUR phases of one
+//     64 x 32 quadrant each (16 MFMAs), and each phase is  { fragment reads + one half tile of LDS-DMA ; barrier ; MFMAs ; barrier };
+//   * the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so on every SIMD one wave's MFMA
+//     segment runs beside the other wave's read / DMA segment: the matrix pipe always has a wave to issue from;
+//   * waits are counted: the DMA of tile t+1's activations and tile t+2's weights stays in flight across the barriers, one
+//     `s_waitcnt vmcnt(4)` per K tile retires what the NEXT tile reads (never vmcnt(0) in the loop);
+//   * products are oriented D^T = W x X^T (weights as the MFMA's row operand): a lane then holds 4 CONSECUTIVE output channels of
+//     one time row, so every epilogue access is 16 bytes (8 for 16-bit rows).
+//
+// Staging schedule (tile t in stage t & 1; X0 / X1 = activation rows 0-127 / 128-255, W0 / W1 = output channels likewise):
+//   phase 0: reads X-quadrant 0 + W-quadrant 0 | DMA X0(t+1) -> other stage     phase 2: reads X-quadrant 1 | DMA W0(t+2) -> this stage
+//   phase 1: reads W-quadrant 1                | DMA X1(t+1) -> other stage     phase 3: (no reads)         | DMA W1(t+2) -> this stage, vmcnt(4)
+// Hazards: a region is re-filled only after every wave's reads of it have retired and a barrier has passed (the W reads of phase 1
+// are waited for BEFORE that phase's barrier, because phase 2 re-fills W one barrier later); data is read one phase after the
+// counted wait (+ barrier) that retires its DMA (guide: "Read a staged buffer one phase AFTER the wait that retires it").
+#pragma once
+#include "gemm.hip.h"
+
+namespace stts {
+
+constexpr int kG16Tile = 256;  // rows and output channels per block
+constexpr int kG16K = 64;      // channels per K tile
+
+template <int PREC>
+__device__ __forceinline__ f32x4 mfma16x16(const f32x4 a, const f32x4 b, const f32x4 c) {
+  if constexpr (PREC == PREC_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// workgroup barrier that neither the compiler nor the machine scheduler moves LDS reads, LDS-DMA or MFMAs across
+#define STTS_G16_BARRIER()                    \
+  do {                                        \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+#define STTS_G16_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)  // lgkmcnt(0) alone (gfx9 encoding: vmcnt 63, expcnt 7)
+#define STTS_G16_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n)&15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))  // vmcnt(n) alone
+
+template <int PREC, bool MSEG>
+__global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
+  static_assert(PREC == PREC_BF16 || PREC == PREC_F16, "16-bit operand modes only");
+  // ALL of the block's LDS is this one array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt before
+  // every fragment read): 2 stages x [X0 | X1 | W0 | W1] x 128 rows x 8 slots of 16 bytes = 128 KB
+  __shared__ f32x4 lds[2 * 4 * 1024];
+
+  // ---- block -> (cout tile, row tile): XCD-aware renumbering + compact row-tile map, as conv_gemm_f32 (speed only)
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+    const unsigned orig = bx + gx * by;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    bx = id % gx;
+    by = id / gx;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int utt = -1, local = 0;
+  {
+    const int t = by + a.tile0;
+    int base = 0;
+    for (int u0 = 0; u0 < a.n_utt && utt < 0; u0 += 64) {
+      const int u = u0 + lane;
+      const int tiles = u < a.n_utt ? (a.seg_off[u + 1] - a.seg_off[u] + kG16Tile - 1) / kG16Tile : 0;
+      int incl = tiles;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+      }
+      const int excl = incl - tiles;
+      const unsigned long long hit = __ballot(t >= base + excl && t < base + incl);
+      if (hit) {
+        const int src = __ffsll((long long)hit) - 1;
+        utt = u0 + src;
+        local = t - base - __shfl(excl, src, 64);
+      }
+      base += __shfl(incl, 63, 64);
+    }
+  }
+  if (utt < 0) return;  // a row tile beyond the batch's last one (the host grid is an upper bound when the offsets live on the device)
+  utt = __builtin_amdgcn_readfirstlane(utt);
+  local = __builtin_amdgcn_readfirstlane(local);
+  const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
+  const int len = hi - lo, rel0 = local * kG16Tile;
+  const int row0 = lo + rel0;
+  if (rel0 >= len) return;
+  const int m0 = bx * kG16Tile;
+  const int wr = wv >> 2, wc = wv & 3;  // time half / cout quarter of this wave; waves w and w + 4 share a SIMD
+
+  // ---- staging cursors (scalar): X runs one tile ahead of the multiplies, W two
+  struct Cur {
+    int s, tap, chunk;
+    const unsigned short* X;  // segment's activations at its first column
+    const unsigned short* W;  // segment's weights at this block's first output channel (and utterance)
+    int ldx, kc, ntaps, dil, pad;
+  };
+  const int nseg = MSEG ? a.nseg : 1;
+  auto load_seg = [&](Cur& c, int s) {
+    const GemmSeg& g = (!MSEG || s == 0) ? a.seg[0] : (s == 1 ? a.seg[1] : a.seg[2]);
+    c.s = s;
+    c.X = reinterpret_cast<const unsigned short*>(g.X) + g.xcol0;
+    c.W = g.W16 + (long)utt * g.w_utt_stride + (long)m0 * g.ntaps * g.kc;
+    c.ldx = g.ldx; c.kc = g.kc; c.ntaps = g.ntaps; c.dil = g.dil; c.pad = g.pad;
+  };
+  auto advance = [&](Cur& c) {  // tap is the inner index (the taps of one chunk re-read almost the same rows: L1 / L2 hits); clamps at the last tile
+    if (c.tap + 1 < c.ntaps) { ++c.tap; return; }
+    if ((c.chunk + 1) * kG16K < c.kc) { c.tap = 0; ++c.chunk; return; }
+    if (MSEG && c.s + 1 < nseg) { load_seg(c, c.s + 1); c.tap = 0; c.chunk = 0; }
+  };
+  Cur cx, cw;
+  load_seg(cx, 0); cx.tap = 0; cx.chunk = 0;
+  cw = cx;
+  int total = a.seg[0].ntaps * (a.seg[0].kc / kG16K);
+  if (MSEG) {
+    if (a.nseg > 1) total += a.seg[1].ntaps * (a.seg[1].kc / kG16K);
+    if (a.nseg > 2) total += a.seg[2].ntaps * (a.seg[2].kc / kG16K);
+  }
+
+  // one LDS-DMA wave-instruction = 64 lanes x 16 B = 8 rows of 128 B; a half tile = 16 of them = 2 per wave
+  const int r8 = lane >> 3, sl = lane & 7;
+  const char* const zeros = reinterpret_cast<const char*>(a.zeros);
+  auto issue_x = [&](const Cur& c, int h, int stage) {
+    const int shift = (c.tap - c.pad) * c.dil;
+    const char* xb = reinterpret_cast<const char*>(c.X + (long)lo * c.ldx + c.chunk * kG16K);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int inst = wv + 8 * q;
+      const int r = inst * 8 + r8;                  // row of the half tile
+      const int logical = sl ^ ((r >> 1) & 7);      // the slot this lane's LDS position holds
+      const int rel = rel0 + h * 128 + r + shift;   // row of the utterance
+      const bool ok = rel >= 0 && rel < len;
+      const char* src = ok ? xb + (unsigned)((rel * c.ldx + logical * 8) * 2) : zeros;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + stage * 4096 + h * 1024 + inst * 64), 16, 0, 0);
+    }
+  };
+  auto issue_w = [&](const Cur& c, int h, int stage) {
+    const int wrow = c.ntaps * c.kc;
+    const char* wb = reinterpret_cast<const char*>(c.W + c.tap * c.kc + c.chunk * kG16K);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int inst = wv + 8 * q;
+      const int r = inst * 8 + r8;
+      const int logical = sl ^ ((r >> 1) & 7);
+      const int n = h * 128 + r;                    // output channel of the block
+      const char* src = wb + (unsigned)((n * wrow + logical * 8) * 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + stage * 4096 + 2048 + h * 1024 + inst * 64), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addressing: lane l holds row (l & 15), k = 8 (l >> 4) .. + 7 of a 16 x 32 block: slot 4 ks + (l >> 4), swizzled
+  const int frow = lane & 15, fsw = (lane >> 1) & 7;
+  const int foff0 = frow * 8 + ((lane >> 4) ^ fsw);        // k sub-step 0
+  const int foff1 = frow * 8 + ((4 + (lane >> 4)) ^ fsw);  // k sub-step 1
+  const int xbase = wr * 1024;                              // this wave's activation half tile
+  const int wbase = 2048 + (wc >> 1) * 1024 + (wc & 1) * 64 * 8;  // its 64 output channels inside their half tile
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 xf[4][2], wf[2][2][2];
+
+  auto read_x = [&](int stage, int xs) {
+    const f32x4* p = lds + stage * 4096 + xbase + xs * 64 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xf[i][0] = p[i * 128 + foff0];
+      xf[i][1] = p[i * 128 + foff1];
+    }
+  };
+  auto read_w = [&](int stage, int cs) {
+    const f32x4* p = lds + stage * 4096 + wbase + cs * 32 * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      wf[cs][j][0] = p[j * 128 + foff0];
+      wf[cs][j][1] = p[j * 128 + foff1];
+    }
+  };
+  auto mma = [&](int xs, int cs) {  // quadrant (xs, cs): 4 x 2 tiles x 2 k sub-steps = 16 MFMAs
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[xs * 4 + i][cs * 2 + j] = mfma16x16<PREC>(wf[cs][j][ks], xf[i][ks], acc[xs * 4 + i][cs * 2 + j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: X(0), W(0), W(1)
+  issue_x(cx, 0, 0);
+  issue_x(cx, 1, 0);
+  advance(cx);
+  issue_w(cw, 0, 0);
+  issue_w(cw, 1, 0);
+  advance(cw);
+  issue_w(cw, 0, 1);
+  issue_w(cw, 1, 1);
+  advance(cw);
+  asm volatile("" ::: "memory");
+  STTS_G16_WAIT_VM(4);  // everything but W(1) has landed (this wave's share; the barrier covers the others')
+  STTS_G16_BARRIER();
+  if (wr == 1) STTS_G16_BARRIER();  // the second wave group runs one barrier behind the first
+
+#pragma unroll 1
+  for (int t = 0; t < total; ++t) {
+    const int st = t & 1;
+    // phase 0
+    read_x(st, 0);
+    read_w(st, 0);
+    issue_x(cx, 0, st ^ 1);
+    STTS_G16_BARRIER();
+    STTS_G16_WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 0);
+    STTS_G16_BARRIER();
+    // phase 1
+    read_w(st, 1);
+    issue_x(cx, 1, st ^ 1);
+    advance(cx);
+    asm volatile("" ::: "memory");
+    STTS_G16_WAIT_LGKM0();  // before the barrier: phase 2 re-fills the W half tiles
+    STTS_G16_BARRIER();
+    mma(0, 1);
+    STTS_G16_BARRIER();
+    // phase 2
+    read_x(st, 1);
+    issue_w(cw, 0, st);
+    STTS_G16_BARRIER();
+    STTS_G16_WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 1);
+    STTS_G16_BARRIER();
+    // phase 3
+    issue_w(cw, 1, st);
+    advance(cw);
+    asm volatile("" ::: "memory");
+    STTS_G16_WAIT_VM(4);  // all but W(t+2): X(t+1) (and W(t+1), older) have landed -> read from the next phase on
+    STTS_G16_BARRIER();
+    mma(1, 0);
+    STTS_G16_BARRIER();
+  }
+  if (wr == 0) STTS_G16_BARRIER();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead DMA of the clamped cursors must not outlive the block
+
+  // ---- epilogue: acc[tm][tn][e] = output (time row wr*128 + tm*16 + (lane & 15), channel wc*64 + tn*16 + 4*(lane >> 4) + e)
+  const int nvalid = len - rel0;
+  const bool hasR = a.R != nullptr, hasY = a.Y != nullptr, hasY16 = a.Y16 != nullptr, hasSS = a.sumsq_part != nullptr;
+  const int act = a.act;
+  const float alpha = a.alpha;
+  const int tl = wr * 128 + frow;                    // + tm * 16
+  const int cl = wc * 64 + 4 * (lane >> 4);          // + tn * 16
+  f32x4 bv[4];
+  bool nok[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = m0 + cl + tn * 16;
+    bv[tn] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    nok[tn] = n < a.N;  // N is a multiple of 4 (launcher)
+  }
+  float* const Yb = hasY ? a.Y + (long)row0 * a.ldy + a.ycol0 + m0 + cl : nullptr;
+  const float* const Rb = hasR ? a.R + (long)row0 * a.ldr + a.rcol0 + m0 + cl : nullptr;
+  unsigned short* const Y16b = hasY16 ? a.Y16 + (long)row0 * a.ldy16 + a.ycol16 + m0 + cl : nullptr;
+  f32x4 ss[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) ss[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tm = 0; tm < 8; ++tm) {
+    const int tr = tl + tm * 16;
+    const bool rok = tr < nvalid;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      f32x4 v = acc[tm][tn] + bv[tn];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+      if (rok && nok[tn]) {
+        if (hasR) v += *reinterpret_cast<const f32x4*>(Rb + (unsigned)(tr * a.ldr + tn * 16));
+        v *= alpha;
+        if (hasY) *reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)) = v;
+        if (hasY16) *reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)) = pack4_16<PREC>(v);
+        ss[tn] += v * v;
+      }
+    }
+  }
+  if (hasSS) {
+    // GRN: per-channel sums of squares over this wave's 128 rows, written as the first of the four 32-row slots the consumer sums
+    // (grn_gx_kernel reads ceil(len / 32) slots per utterance); the other three slots of the group get zeros
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      f32x4 s = ss[tn];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += __shfl_xor(s[e], o, 64);
+      if (frow < 4 && nok[tn]) {
+        const int sub = local * 8 + wr * 4 + frow;  // 32-row slot of the utterance
+        if (sub * 32 < len) {
+          const long slot = (long)utt * a.ss_stride + sub;
+          *reinterpret_cast<f32x4*>(a.sumsq_part + slot * a.ld_ss + m0 + cl + tn * 16) = frow == 0 ? s : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+}
+
+// Can this contraction run on conv_gemm16_kernel?  16-bit activation rows, store epilogue, every segment's channels a multiple of 64,
+// cout padded to 256, N a multiple of 4, host offsets known (compact grid).
+inline bool gemm16_eligible(const GemmArgs& a, int epi, int npad) {
+  if (epi != EPI_STORE || a.prec == PREC_F32 || !a.x16 || !a.seg_host || a.xaff || npad % kG16Tile != 0 || a.N % 4 != 0) return false;
+  if (a.ldy % 4 || a.ycol0 % 4 || a.ldr % 4 || a.rcol0 % 4 || a.ldy16 % 4 || a.ycol16 % 4 || a.ld_ss % 4) return false;
+  for (int i = 0; i < a.nseg; ++i)
+    if (a.seg[i].kc % kG16K != 0 || a.seg[i].ldx % 8 != 0 || a.seg[i].xcol0 % 8 != 0 || !a.seg[i].W16) return false;
+  return true;
+}
+
+// rows: exact row-tile count from the host offsets (an upper bound when they are capacities)
+inline int launch_conv_gemm16(hipStream_t st, const GemmArgs& a, int npad, int n_utt) {
+  STTS_CHECK(gemm16_eligible(a, EPI_STORE, npad), "conv_gemm16: contraction not eligible");
+  long rt = 0;
+  for (int u = 0; u < n_utt; ++u) rt += ceil_div(a.seg_host[u + 1] - a.seg_host[u], kG16Tile);
+  GemmArgs as = a;
+  as.n_utt = n_utt;
+  as.compact = 1;
+  as.tile0 = 0;
+  as.tiles_y = (int)rt;
+  as.ksplit = 1;
+  if (!as.zeros) as.zeros = zero_page();
+  GemmProfiler& prof = gemm_profiler();
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof.on) {
+    e0 = prof.next();
+    e1 = prof.next();
+    const double fl = gemm_algorithmic_flops(a);
+    prof.add("conv_gemm16_kernel", 0, fl, fl, 0.0);
+  }
+  const dim3 grid(npad / kG16Tile, (unsigned)rt), block(512);
+  if (a.prec == PREC_BF16) {
+    if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm16_kernel<PREC_BF16, false>), grid, block, st, e0, e1, as);
+    else STTS_LAUNCH_TIMED((conv_gemm16_kernel<PREC_BF16, true>), grid, block, st, e0, e1, as);
+  } else {
+    if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm16_kernel<PREC_F16, false>), grid, block, st, e0, e1, as);
+    else STTS_LAUNCH_TIMED((conv_gemm16_kernel<PREC_F16, true>), grid, block, st, e0, e1, as);
+  }
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace stts

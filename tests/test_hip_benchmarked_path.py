@@ -107,16 +107,18 @@ def test_cfg2_batch8_reproduces_the_reference_waveform(hip):
     assert errs.max() < 1e-3, errs
 
 
-def test_bench_inputs_utterance0_matches_the_oracle(hip, weights):
-    """bench.py's own cfg2 batch: staged B = 8 run vs the oracle on utterance 0 (the oracle takes ~1-2 s for it)."""
+def test_bench_inputs_match_the_oracle(hip, weights):
+    """bench.py's own cfg2 batch (eight DISTINCT utterances at R = 7 680): staged B = 8 run vs the oracle on utterances 0, 3 and 7 (the
+    first, one in the middle of a 128-row tile sequence, the last; the oracle takes ~1-2 s for each)."""
     from oracle import stylish_oracle as O
 
     sys.path.insert(0, ROOT)
     import bench
 
-    assert (bench.BATCH, bench.T4) == (8, 960)
-    inp = bench.synth_inputs(0, torch.device("cuda", 0))
-    B, T4 = bench.BATCH, bench.T4
+    a = bench.parse_args([])
+    B, T4 = a.batch, 4 * a.mel_frames
+    assert (B, T4) == (8, 960)
+    inp = bench.cfg2_inputs(0, torch.device("cuda", 0), B, T4)
     s = segs([T4] * B)
     x = hip.decoder(s, inp["asr"], inp["pitch"], inp["energy"], inp["style"])
     mel = hip.prior_flow(s, x, inp["style"], inp["prior_noise"])
@@ -128,7 +130,7 @@ def test_bench_inputs_utterance0_matches_the_oracle(hip, weights):
     assert torch.equal(fused, audio)  # bench.py's call == the staged composition
     h = inp["host"]
     w = weights["speech_predictor"]
-    for u in (0,):
+    for u in (0, 3, 7):
         sl = slice(u * T4, (u + 1) * T4)
         nz = dict(prior_noise=h["nz"]["prior_noise"][u : u + 1], src_noise=h["nz"]["src_noise"][u : u + 1], init_phase=h["nz"]["init_phase"])
         a_in, p_in, e_in, s_in = h["asr"][sl].T[None].copy(), h["pitch"][sl][None], h["energy"][sl][None], h["style"][u : u + 1]
