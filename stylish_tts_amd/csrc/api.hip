@@ -166,7 +166,7 @@ int stts_vocoder_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* se
                          float* logamp_out, float* phase_out, int ld_lp, void* ws, size_t ws_bytes) {
   API_BEGIN
   SEG_CHECK(STTS_W_GENERATOR);
-  STTS_CHECK(ld_mel % 4 == 0 && ld_har % 32 == 0 && ld_har >= round_up(kBins, 32), "har/mel leading dimension must cover 1056 columns, multiple of 32");
+  STTS_CHECK(ld_mel % 4 == 0 && ld_har % 32 == 0 && ld_har >= har_ld(c), "har/mel leading dimension: ld_har must be a multiple of 32 covering %d columns (the prior convs' packed input width)", har_ld(c));
   STTS_CHECK(!logamp_out || ld_lp >= kBins, "ld_lp too small");
   Arena a(ws, ws_bytes);
   return vocoder_forward(c, st, s, mel, ld_mel, style, har_spec, har_phase, ld_har, audio_out, logamp_out, phase_out, ld_lp, a);

@@ -68,6 +68,7 @@ struct GemmArgs {
   int n_utt;
   int compact;          // grid.y enumerates only the row tiles that exist (sum over utterances), grid.z = split-K slice
   int tile0, tiles_y;   // compact: this launch covers global row tiles [tile0, tile0 + tiles_y)
+  int gemm16_gx;        // conv_gemm16_kernel (persistent blocks): cout tiles of the virtual grid
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
   int prec;               // PREC_F32 / PREC_BF16 / PREC_F16 operands (every segment then carries W16)
@@ -988,6 +989,13 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
     }                                                                                             \
   } while (0)
 
+// conv_gemm16_kernel (gemm16.hip.h): the 16-bit-row store contractions of large batches
+inline bool gemm16_eligible(const GemmArgs& a, int epi, int npad);
+inline long gemm16_tiles(const GemmArgs& a, int npad, int n_utt);
+template <int ABL>
+inline int launch_conv_gemm16(hipStream_t st, const GemmArgs& a, int npad, int n_utt);
+
+#ifndef STTS_GEMM_NO_LAUNCHER  // (probes that only need the types and conv_gemm16_kernel skip the ~50 instantiations below)
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = PREC_F32>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
@@ -1038,9 +1046,18 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     STTS_CHECK(a.seg[i].kc % 32 == 0 && a.seg[i].ldx % 4 == 0 && a.seg[i].xcol0 % 4 == 0, "conv_gemm: segment %d misaligned (kc %d ldx %d xcol0 %d)", i,
                a.seg[i].kc, a.seg[i].ldx, a.seg[i].xcol0);
   }
+  // (a segment may read its last padded channels from the NEXT row - a column slice whose width is not a multiple of 32, e.g. the
+  //  halves of a 96-channel flow: the packed weights are zero there and the data finite; conv_gemm16_kernel's descriptors do not allow it)
   if (a.x16)
     for (int i = 0; i < a.nseg; ++i)
       STTS_CHECK(a.prec != PREC_F32 && a.seg[i].ldx % 8 == 0 && a.seg[i].xcol0 % 8 == 0, "conv_gemm: 16-bit activation rows need ldx / xcol0 multiples of 8 (segment %d)", i);
+  // 16-bit activation rows, store epilogue, at least ~one 256 x 256 tile per CU: the persistent LDS-DMA kernel (gemm16.hip.h).
+  // force_tile 19 selects it whatever the size (tests), any other forced tile keeps the launch on conv_gemm_f32.
+  if ((force_tile == 0 || force_tile == 19) && gemm16_eligible(a, epi, npad)) {
+    static const long min_tiles = getenv("STTS_GEMM16_MIN_TILES") ? atol(getenv("STTS_GEMM16_MIN_TILES")) : 192;
+    if (force_tile == 19 || gemm16_tiles(a, npad, n_utt) >= min_tiles) return launch_conv_gemm16<0>(st, a, npad, n_utt);
+  }
+  STTS_CHECK(force_tile != 19, "conv_gemm: tile 19 (conv_gemm16_kernel) needs 16-bit activation rows, a store epilogue, channels in multiples of 64 and cout padded to 256");
   constexpr int kCUs = 256;
   const int mt = npad / 128;
   auto row_tiles = [&](int bn) -> long {  // exact when the host offsets are known (mixed lengths)
@@ -1235,5 +1252,6 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   STTS_HIP(hipGetLastError());
   return 0;
 }
+#endif  // STTS_GEMM_NO_LAUNCHER
 
 }  // namespace stts

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "elementwise.hip.h"
 #include "gemm.hip.h"
+#include "gemm16.hip.h"
 #include "signal.hip.h"
 #include "phoneme.hip.h"
 #include "wn_layer.hip.h"
@@ -133,6 +134,7 @@ struct stts_ctx {
   int* d_err = nullptr;
   int ready = 0;  // STTS_W_* components finalized
   int prec = 0;   // contraction operand precision (stts::PREC_*), fixed before the first finalize
+  int kc_align = 32;  // input channels of a packed conv are padded to this (64 while the frame path is packed for a 16-bit mode: conv_gemm16_kernel's K tile)
   // shared tables
   float* hann = nullptr;      // periodic Hann(win)
   float2* twiddle = nullptr;  // exp(-2 pi i m / n_fft), m < n_fft/2
@@ -312,7 +314,7 @@ inline int pack_plain(stts_ctx* c, const std::string& p, bool has_bias, int cin_
   const HostTensor* b = has_bias ? find(c, p + ".bias") : nullptr;
   if (has_bias && !b) return fail("missing weight '%s.bias'", p.c_str());
   if (cin_n < 0) cin_n = (int)w.shape[1] - cin_lo;
-  return pack_rows(c, w, b, plain_rows((int)w.shape[0]), cin_lo, cin_n, round_up(cin_n, 32), (int)w.shape[0], out, scale);
+  return pack_rows(c, w, b, plain_rows((int)w.shape[0]), cin_lo, cin_n, round_up(cin_n, c->kc_align), (int)w.shape[0], out, scale);
 }
 
 inline int upload_table(stts_ctx* c, StyleTable* t) {
@@ -377,7 +379,7 @@ inline int pack_winograd(stts_ctx* c, const HostTensor& w, const HostTensor* bia
 inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout, StyleTable* table, AdainBlockW* o) {
   o->cin = cin;
   o->cout = cout;
-  o->kcin = round_up(cin, 32);
+  o->kcin = round_up(cin, c->kc_align);
   STTS_TRY(pack_plain(c, p + ".conv1", true, 0, cin, &o->conv1));
   o->w1 = WinoConv();
   if (c->prec == PREC_F32) {
@@ -514,6 +516,12 @@ inline int finalize_frame(stts_ctx* c, int which) {
   STTS_CHECK(d.gen_hidden > 0 && d.gen_hidden % 32 == 0 && d.gen_inter > 0 && d.gen_inter % 32 == 0,
              "generator.hidden_dim / conv_intermediate_dim must be multiples of 32");
   const std::string sp = "speech_predictor.";
+  // 16-bit operand modes: input channels padded to 64 (the K tile of conv_gemm16_kernel); the stages size their rows from the packed kc
+  struct AlignReset {
+    stts_ctx* c;
+    ~AlignReset() { c->kc_align = 32; }
+  } align_reset{c};
+  c->kc_align = c->prec != PREC_F32 ? 64 : 32;
   // tables
   c->cur_tag = 0;
   if (!c->hann) {
@@ -973,8 +981,9 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
                            const float* style, float* x_out, int ld_x, Arena& ws) {
   const stts_model_dims& d = c->d;
   const long R = s.rows();
-  const int ccat = d.dec_hidden + d.dec_residual + 2, ldcat = round_up(ccat, 32);  // 578 -> 608
-  const int cenc = d.inter_dim + 2, ldenc = round_up(cenc, 32);                    // 130 -> 160
+  const int ccat = d.dec_hidden + d.dec_residual + 2, ldcat = c->dec[1].kcin;  // 578 -> 608 (640 in the 16-bit modes): the packed input width
+  const int cenc = d.inter_dim + 2, ldenc = c->dec[0].kcin;                    // 130 -> 160 (192)
+  STTS_CHECK(ldcat >= ccat && ldenc >= cenc, "decoder_forward: packed widths %d / %d do not cover %d / %d channels", ldcat, ldenc, ccat, cenc);
   // (dec[0] runs on the encoder-input width, the other blocks on the concat width: scratch is sized by the wider of the two - a config
   //  with inter_dim > hidden_dim + residual_dim is legal)
   const int ldwide = std::max(ldenc, ldcat);
@@ -1532,12 +1541,15 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   return vocoder_body(c, st, s, mel, ld_mel, style, headA, headP, audio, logamp_out, phase_out, ld_lp, ws);
 }
 
+// row stride of the harmonic spectra: the prior convs' packed input width (1056; 1088 in the 16-bit modes)
+inline int har_ld(const stts_ctx* c) { return std::max(round_up(kBins, 32), c->amp_prior.kc); }
+
 inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* asr, int ld_asr, const float* pitch, const float* energy,
                       const float* style, const float* prior_noise, const float* src_noise, const float* init_phase, int batch_scope,
                       float* audio, void* wsp, size_t ws_bytes) {
   const long R = s.rows();
   Arena top(wsp, ws_bytes);
-  const int ldh = round_up(kBins, 32), hc = c->d.gen_hidden + c->d.gen_hidden / 2, dh = c->d.dec_hidden;
+  const int ldh = har_ld(c), hc = c->d.gen_hidden + c->d.gen_hidden / 2, dh = c->d.dec_hidden;
   float* x = top.get<float>(R * dh);
   float* mel = top.get<float>(R * dh);
   float* hs = top.get<float>(R * ldh);
@@ -1604,7 +1616,7 @@ inline size_t frame_workspace_bytes(const stts_ctx* cc, int64_t R, int n_utt, in
   (void)frame_path(c, nullptr, s, nullptr, c->d.inter_dim, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, fake, cap);
   {  // the staged entry points start their carving at offset 0; vocoder_forward with its own head buffers is the largest of them
     Arena a(fake, cap);
-    (void)vocoder_forward(c, nullptr, s, nullptr, c->d.dec_hidden, nullptr, nullptr, nullptr, round_up(kBins, 32), nullptr, nullptr, nullptr, 0, a);
+    (void)vocoder_forward(c, nullptr, s, nullptr, c->d.dec_hidden, nullptr, nullptr, nullptr, har_ld(c), nullptr, nullptr, nullptr, 0, a);
     Arena b(fake, cap);
     (void)decoder_forward(c, nullptr, s, nullptr, c->d.inter_dim, nullptr, nullptr, nullptr, nullptr, c->d.dec_hidden, b);
   }

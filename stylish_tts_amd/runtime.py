@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .config import load_model_config
 
-N_BINS_LD = 1056  # 1025 bins padded to a multiple of 32 floats
+N_BINS_LD = 1056  # 1025 bins padded to a multiple of 32 floats (spectrum rows of an fp32 engine; HipModel.har_ld is the engine's own stride)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -69,6 +69,8 @@ class HipModel:
         self.ctx = h
         self.precision = precision
         _lib.check(self.lib.stts_set_precision(self.ctx, self.PRECISIONS[precision]))
+        # row stride of the harmonic spectra = the prior convs' packed input width: 1025 bins padded to 32 (fp32) or 64 (16-bit modes)
+        self.har_ld = N_BINS_LD if precision == "f32" else 1088
         # grow-only workspaces, one per launch stream (stages issued on different streams may run concurrently)
         self._ws: Dict[int, torch.Tensor] = {}
         self._pws: Dict[int, torch.Tensor] = {}
@@ -139,12 +141,12 @@ class HipModel:
         return (mel, zp, zf) if return_z else mel
 
     def harmonic_stft(self, seg: Segments, pitch, src_noise, init_phase, batch_scope=True, return_signal=False):
-        spec = self._f32(seg.rows, N_BINS_LD)
-        phase = self._f32(seg.rows, N_BINS_LD)
+        spec = self._f32(seg.rows, self.har_ld)
+        phase = self._f32(seg.rows, self.har_ld)
         sig = self._f32(seg.rows * 75) if return_signal else None
         ws = self.workspace(seg)
         _lib.check(self.lib.stts_harmonic_stft(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(pitch), _ptr(src_noise),
-                                               _ptr(init_phase), int(batch_scope), _ptr(sig), _ptr(spec), _ptr(phase), N_BINS_LD, _ptr(ws),
+                                               _ptr(init_phase), int(batch_scope), _ptr(sig), _ptr(spec), _ptr(phase), self.har_ld, _ptr(ws),
                                                ws.numel()))
         return (spec, phase, sig) if return_signal else (spec, phase)
 

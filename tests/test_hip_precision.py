@@ -78,6 +78,14 @@ def rounded_oracle():
         (256, 128, 1, 1, [128], 118),
         (578, 512, 3, 1, [200, 37, 129], 118),
         (768, 1024, 7, 1, [300, 17], 118),
+        # ... and conv_gemm16_kernel (tile 19: persistent 256 x 256 blocks, LDS-DMA through buffer descriptors, K tiles of 64 channels): deep and
+        # single K tiles, ragged tails, utterances shorter than a tile, taps reaching across both ends, dilation
+        (768, 1024, 7, 1, [300, 517, 2], 119),
+        (512, 1536, 1, 1, [700, 1], 119),
+        (64, 256, 1, 1, [5, 256], 119),
+        (1024, 256, 7, 1, [513], 119),
+        (192, 512, 3, 1, [260, 255, 257, 31], 119),
+        (64, 256, 7, 3, [77, 5], 119),
     ],
 )
 def test_conv1d_16bit_matches_rounded_oracle(hip32, rounded_oracle, prec, cin, cout, k, dil, lengths, tile):
