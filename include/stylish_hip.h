@@ -76,8 +76,9 @@ int stts_finalize_weights(stts_ctx* ctx, int which);
  * durations are integers (bit-exact against the fp32 reference in every mode) and those stages are latency-bound. */
 enum { STTS_PREC_F32 = 0, STTS_PREC_BF16 = 1, STTS_PREC_F16 = 2 };
 int stts_set_precision(stts_ctx* ctx, int precision);
-/* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz
- * (the reference raises there, models/generator.py:285).  Synchronises the stream. */
+/* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz (the reference raises there,
+ * models/generator.py:285), 2 = a token id outside the embedding table, 4 = an utterance
+ * too short for the STFT's reflect padding.  Synchronises the stream. */
 int stts_check_status(stts_ctx* ctx, void* stream);
 
 /* Workspace the frame-rate stages need for `rows` vocoder frames (sum of T4) in `n_utt` utterances,
@@ -123,12 +124,19 @@ int stts_vocoder_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* 
                          const float* mel, int ld_mel, const float* style, const float* har_spec, const float* har_phase, int ld_har,
                          float* audio_out, float* logamp_out, float* phase_out, int ld_lp, void* ws, size_t ws_bytes);
 
+/* Utterance offsets of a frame-rate call may be CAPACITY SEGMENTS (seg_flags & STTS_SEG_CAPACITY): the host array then holds
+ * upper bounds (cumulative capacities - every buffer, workspace and grid is sized by them), the device array the real offsets,
+ * which only exist on the device (stts_frame_offsets).  Rows of utterance u are [dev[u], dev[u+1]) - packed, dev[u] <= host[u] -
+ * so outputs are packed by the REAL lengths and the caller reads the device offsets once, together with the output.  This is
+ * what removes the host round trip between the duration predictor and everything frame-rate (train/test_onnx.py:65-66). */
+enum { STTS_SEG_CAPACITY = 1 };
+
 /* The frame-rate hot path in one call: decoder -> prior -> reverse flow -> post_flow -> harmonic source ->
- * STFT -> vocoder -> iSTFT (models/speech_predictor.py:92-118).  This is the benchmarked unit. */
+ * STFT -> vocoder -> iSTFT (models/speech_predictor.py:92-118).  This is the benchmarked unit.  seg_flags: 0 or STTS_SEG_CAPACITY. */
 int stts_frame_path(stts_ctx* ctx, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev,
                     const float* asr, int ld_asr, const float* pitch, const float* energy, const float* style,
                     const float* prior_noise, const float* src_noise, const float* init_phase, int batch_scope,
-                    float* audio_out, void* ws, size_t ws_bytes);
+                    float* audio_out, void* ws, size_t ws_bytes, int seg_flags);
 
 /* ---- phoneme-rate predictors.  Sequences are packed: tok_off[n_utt+1] token offsets, tokens int64 [n_tok]. ---- */
 size_t stts_phoneme_workspace_bytes(const stts_ctx* ctx, int64_t n_tokens, int64_t n_frames, int n_utt);
@@ -155,7 +163,17 @@ int stts_duration_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t*
 int stts_pitch_energy_forward(stts_ctx* ctx, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
                               const int32_t* frm_off_host, const int32_t* frm_off_dev, const int32_t* dur, const float* pe_enc, int ld_enc,
                               const float* pe_style, float* f0_out, float* energy_out, float* prosody_out, float* cross_out, void* ws,
-                              size_t ws_bytes);
+                              size_t ws_bytes, int seg_flags /* 0 or STTS_SEG_CAPACITY: applies to the frame offsets */);
+
+/* The host side of DurationProcessor between the two models (train/test_onnx.py:65-66 reads the durations on the host to size the
+ * alignment), on the device: from the integer durations of a packed batch, off_T [n_utt+1] = cumulative mel frames per utterance,
+ * off_T4 = 4 x (vocoder frames), need [n_utt] = frames of each utterance.  cap_off [n_utt+1] (device): the capacity layout the caller
+ * sized its buffers by (mel frames).  An utterance that exceeds its capacity is truncated to it - every later stage stays in
+ * bounds, its output is invalid - and need[u] > capacity tells the caller, who reads `need` once together with the output, to repeat
+ * the call with capacities >= need (no shared error state: calls may be in flight on several streams).  All pointers are device
+ * pointers; nothing synchronises. */
+int stts_frame_offsets(stts_ctx* ctx, void* stream, int n_utt, const int32_t* tok_off_dev, const int32_t* dur, const int32_t* cap_off_dev,
+                       int32_t* off_T_dev, int32_t* off_T4_dev, int32_t* need_dev);
 
 /* DurationProcessor.prediction_to_duration (train/utils.py:468-474): logits [n_rows, ld >= 16] -> int32 durations. */
 int stts_duration_decode(void* stream, const float* logits, int ld, int n_rows, int32_t* dur_out);

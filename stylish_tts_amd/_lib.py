@@ -64,12 +64,13 @@ SIGNATURES = {
     "stts_prior_flow_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _SZ]),
     "stts_harmonic_stft": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _SZ]),
     "stts_vocoder_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _SZ]),
-    "stts_frame_path": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ]),
+    "stts_frame_path": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _I]),
+    "stts_frame_offsets": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "stts_phoneme_workspace_bytes": (_SZ, [_P, _I64, _I64, _I]),
     "stts_text_encoder_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _SZ]),
     "stts_text_style_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _SZ]),
     "stts_duration_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ]),
-    "stts_pitch_energy_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _SZ]),
+    "stts_pitch_energy_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _SZ, _I]),
     "stts_duration_decode": (_I, [_P, _P, _I, _I, _P]),
     "stts_duration_to_alignment": (_I, [_P, _P, _I, _I, _P]),
     "stts_length_regulate": (_I, [_P, _P, _I, _P, _P, _P, _I64, _I, _P, _I, _I, _P, _I, _P]),

@@ -112,6 +112,7 @@ int stts_check_status(stts_ctx* c, void* stream) {
   if (e) {
     STTS_HIP(hipMemset(c->d_err, 0, sizeof(int)));
     if (e == 2) return stts::fail("text encoder: token id outside [0, tokens)");
+    if (e == 4) return stts::fail("harmonic source: an utterance is too short for the STFT's reflect padding (needs more than %d samples)", kNfft / 2);
     return stts::fail("harmonic source: a frame is voiced (f0 > 10 Hz) but no f0 exceeds 20 Hz (reference raises: models/generator.py:285)");
   }
   return 0;
@@ -175,9 +176,10 @@ int stts_vocoder_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* se
 
 int stts_frame_path(stts_ctx* c, void* stream, int n_utt, const int32_t* seg_off_host, const int32_t* seg_off_dev, const float* asr, int ld_asr,
                     const float* pitch, const float* energy, const float* style, const float* prior_noise, const float* src_noise,
-                    const float* init_phase, int batch_scope, float* audio_out, void* ws, size_t ws_bytes) {
+                    const float* init_phase, int batch_scope, float* audio_out, void* ws, size_t ws_bytes, int seg_flags) {
   API_BEGIN
   SEG_CHECK(STTS_W_DECODER | STTS_W_FLOW | STTS_W_GENERATOR);
+  s.cap = (seg_flags & STTS_SEG_CAPACITY) != 0;
   STTS_CHECK(ld_asr >= c->d.inter_dim && ld_asr % 4 == 0, "bad ld_asr");
   return frame_path(c, st, s, asr, ld_asr, pitch, energy, style, prior_noise, src_noise, init_phase, batch_scope, audio_out, ws, ws_bytes);
   API_END
@@ -193,7 +195,18 @@ int stts_length_regulate(stts_ctx* c, void* stream, int n_utt, const int32_t* du
   hipLaunchKernelGGL(frame_token_map_kernel, dim3(n_utt), dim3(256), 0, st, dur, tok_off, frm_off, rep, src_row_ws);
   const long work = n_frames * (C / 4);
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long>(2048, std::max<long>(1, (work + 255) / 256))), dim3(256), 0, st, enc, ld_enc,
-                     src_row_ws, out, ld_out, 0, C, (int)n_frames);
+                     src_row_ws, out, ld_out, 0, C, (int)n_frames, frm_off + n_utt);  // n_frames may be a capacity: the real count is frm_off[n_utt]
+  STTS_HIP(hipGetLastError());
+  return 0;
+  API_END
+}
+
+int stts_frame_offsets(stts_ctx* c, void* stream, int n_utt, const int32_t* tok_off_dev, const int32_t* dur, const int32_t* cap_off_dev,
+                       int32_t* off_T_dev, int32_t* off_T4_dev, int32_t* need_dev) {
+  API_BEGIN
+  STTS_CHECK(c && n_utt > 0 && tok_off_dev && dur && cap_off_dev && off_T_dev && off_T4_dev && need_dev, "frame_offsets: bad argument");
+  STTS_HIP(hipSetDevice(c->device));
+  hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dur, tok_off_dev, n_utt, cap_off_dev, off_T_dev, off_T4_dev, need_dev);
   STTS_HIP(hipGetLastError());
   return 0;
   API_END
@@ -344,13 +357,14 @@ int stts_duration_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* t
 int stts_pitch_energy_forward(stts_ctx* c, void* stream, int n_utt, const int32_t* tok_off_host, const int32_t* tok_off_dev,
                               const int32_t* frm_off_host, const int32_t* frm_off_dev, const int32_t* dur, const float* pe_enc, int ld_enc,
                               const float* pe_style, float* f0_out, float* energy_out, float* prosody_out, float* cross_out, void* ws,
-                              size_t ws_bytes) {
+                              size_t ws_bytes, int seg_flags) {
   API_BEGIN
   PH_CHECK(STTS_W_PITCH_ENERGY);
   STTS_TRY(seg_ok(n_utt, tok_off_host, tok_off_dev));
   STTS_TRY(seg_ok(n_utt, frm_off_host, frm_off_dev));
   STTS_CHECK(ld_enc >= c->d.pe_inter && ld_enc % 4 == 0, "bad ld_enc");
   Seg sp{n_utt, tok_off_host, tok_off_dev}, sf{n_utt, frm_off_host, frm_off_dev};
+  sf.cap = (seg_flags & STTS_SEG_CAPACITY) != 0;
   Arena a(ws, ws_bytes);
   return pitch_energy_forward(c, M, st, sp, sf, dur, pe_enc, ld_enc, pe_style, f0_out, energy_out, prosody_out, cross_out, a);
   API_END

@@ -267,10 +267,12 @@ struct LnIn {
 };
 __global__ void __launch_bounds__(256) row_layernorm_kernel(const float* __restrict__ X, int ldx, int C, int n_rows,
                                                             const int* __restrict__ row_utt, float eps, int adaptive, int nout,
-                                                            LnOut o0, LnOut o1, int act, LnIn in) {
+                                                            LnOut o0, LnOut o1, int act, LnIn in, const int* __restrict__ n_rows_dev) {
+  // n_rows_dev (optional): the batch's real row count on the device - n_rows is then an upper bound (capacity segments) and the rows
+  // beyond it, whose row_utt entries nobody wrote, are skipped
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= n_rows) return;
+  if (row >= n_rows || (n_rows_dev && row >= *n_rows_dev)) return;
   const float* x = X + (long)row * ldx;
   float4 v[8];
   const int nv = C / 4;
@@ -536,11 +538,43 @@ __global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restri
 // Here: gather of the phoneme encoding into time-major rows.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ enc, int ld_enc, const int* __restrict__ src_row,
-                                                          float* __restrict__ Y, int ldy, int ycol0, int C, int n_rows) {
+                                                          float* __restrict__ Y, int ldy, int ycol0, int C, int n_rows, const int* __restrict__ n_rows_dev) {
+  if (n_rows_dev) n_rows = min(n_rows, *n_rows_dev);  // capacity segments: src_row is filled for the real rows only
   const int nv = C / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)n_rows * nv; i += (long)gridDim.x * 256) {
     const int r = (int)(i / nv), c4 = (int)(i % nv) * 4;
     *reinterpret_cast<float4*>(Y + (long)r * ldy + ycol0 + c4) = *reinterpret_cast<const float4*>(enc + (long)src_row[r] * ld_enc + c4);
+  }
+}
+
+// Frame offsets of a batch from the predicted durations, on the device (the reference reads the durations on the host to size the
+// alignment matrix: train/test_onnx.py:65-66, train/utils.py:476-489): T_u = sum of utterance u's durations, off_T = cumulative
+// sum, off_T4 = 4 x.  cap_off [n_utt + 1]: the caller's CAPACITY layout (upper bounds the host sized every buffer and grid by);
+// need [n_utt] receives T_u itself.  An utterance that does not fit its capacity is truncated to it, so everything downstream
+// stays in bounds; the caller, who reads `need` together with the output, sees need[u] > capacity and repeats the call.
+// (No shared error word: several calls may be in flight on different streams.)  One block; a wave per utterance sums its
+// durations, one thread scans.
+__global__ void __launch_bounds__(1024) frame_offsets_kernel(const int* __restrict__ dur, const int* __restrict__ tok_off, int n_utt,
+                                                             const int* __restrict__ cap_off, int* __restrict__ off_T, int* __restrict__ off_T4,
+                                                             int* __restrict__ need) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int u = wave; u < n_utt; u += 16) {
+    int s = 0;
+    for (int i = tok_off[u] + lane; i < tok_off[u + 1]; i += 64) s += max(dur[i], 0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) need[u] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    off_T[0] = 0;
+    off_T4[0] = 0;
+    for (int u = 0; u < n_utt; ++u) {
+      run += min(need[u], cap_off[u + 1] - cap_off[u]);
+      off_T[u + 1] = run;
+      off_T4[u + 1] = 4 * run;
+    }
   }
 }
 

@@ -69,6 +69,8 @@ struct GemmArgs {
   int compact;          // grid.y enumerates only the row tiles that exist (sum over utterances), grid.z = split-K slice
   int tile0, tiles_y;   // compact: this launch covers global row tiles [tile0, tile0 + tiles_y)
   int gemm16_gx;        // conv_gemm16_kernel (persistent blocks): cout tiles of the virtual grid
+  int capacity;         // seg_host holds UPPER BOUNDS of the utterance lengths (the real offsets live only on the device): grids are sized from
+                        // them and blocks beyond the device-side tile count exit; plans that need exact host offsets are off
   int rows_total, wrows;  // host side: rows of the call, un-padded weight rows (FLOP accounting only)
   int tune;               // experiment switches (tools/gemm_bench.py ablations)
   int prec;               // PREC_F32 / PREC_BF16 / PREC_F16 operands (every segment then carries W16)
@@ -187,7 +189,23 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // tiles with the cout tile as the fastest index: all cout tiles of a row tile then share their X rows in one L2.
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   {
-    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    unsigned gy = gridDim.y;
+    if (a.capacity) {
+      // Capacity segments: grid.y counts the row tiles of the host's UPPER BOUNDS; the real count comes from the device offsets.
+      // Blocks beyond it leave at once, and the XCD-aware renumbering below runs over the real tiles only - over the padded
+      // grid the empty tail would fall to the last XCDs and leave them idle (measured: +32 % at 1.4 x capacity).
+      const int lane_ = threadIdx.x & 63;
+      int tot = 0;
+      for (int u0 = 0; u0 < a.n_utt; u0 += 64) {
+        const int u = u0 + lane_;
+        tot += u < a.n_utt ? (a.seg_off[u + 1] - a.seg_off[u] + BN - 1) / BN : 0;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+      gy = (unsigned)tot;
+      if ((unsigned)by >= gy) return;
+    }
+    const unsigned gx = gridDim.x, nwg = gx * gy * gridDim.z;
     const unsigned orig = bx + gx * (by + gy * bz);
     const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
@@ -225,6 +243,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       }
       base += __shfl(incl, 63, 64);
     }
+    if (!done) return;  // a row tile beyond the batch's last one: the host grid is an upper bound when the offsets live on the device
     by = local;
   } else {
     utt = bz / ksplit;
@@ -1085,7 +1104,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     const long whole = blocks / kCUs;
     p.full_rt = rt;
     p.cost = std::ceil((double)blocks / kCUs);
-    if (splittable && a.seg_host && whole >= 1 && blocks % kCUs != 0) {
+    if (splittable && a.seg_host && !a.capacity && whole >= 1 && blocks % kCUs != 0) {  // (the remainder launch needs exact host offsets)
       const long full_rt = whole * kCUs / mt, rem_blocks = (rt - full_rt) * mt;
       const int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, kCUs / std::max<long>(rem_blocks, 1)));
       if (ksp >= 2 && full_rt > 0) {

@@ -50,7 +50,7 @@ __device__ __forceinline__ f32x4 g16_mfma(const f32x4 a, const f32x4 b, const f3
 #define STTS_G16_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n)&15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))  // vmcnt(n) alone
 
 // ABL (tools/probes/gemm16_probe.hip only; results invalid, timing only): 1 no LDS-DMA in the loop, 2 no fragment reads in the loop,
-// 4 no MFMAs, 8 no epilogue stores, 16 no barriers in the loop, 32 no s_setprio around the MFMA clusters
+// 4 no MFMAs, 8 no epilogue stores, 16 no barriers in the loop, 32 no s_setprio around the MFMA clusters, 64 nontemporal epilogue stores
 template <int PREC, bool MSEG, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
   static_assert(PREC == PREC_BF16 || PREC == PREC_F16, "16-bit operand modes only");
@@ -80,7 +80,18 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
   // ---- persistent blocks: block b walks the tiles b, b + gridDim.x, ... of the virtual grid (cout tiles x row tiles), re-numbered
   // XCD-aware like conv_gemm_f32 (workgroups b and b + 8 share an XCD, so do the virtual blocks they walk; speed only).
   // The epilogue's stores of one tile drain while the next tile's K loop runs.
-  const unsigned gx = a.gemm16_gx, nvirt = gx * (unsigned)a.tiles_y;
+  const unsigned gx = a.gemm16_gx;
+  unsigned nvirt = gx * (unsigned)a.tiles_y;
+  if (a.capacity) {  // capacity segments: tiles_y counts the host's upper bounds; walk (and renumber over) the real row tiles only
+    int tot = 0;
+    for (int u0 = 0; u0 < a.n_utt; u0 += 64) {
+      const int u = u0 + lane;
+      tot += u < a.n_utt ? (a.seg_off[u + 1] - a.seg_off[u] + kG16Tile - 1) / kG16Tile : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    nvirt = gx * (unsigned)__builtin_amdgcn_readfirstlane(tot);
+  }
   for (unsigned v = blockIdx.x; v < nvirt; v += gridDim.x) {
     int bx, by;
     {
@@ -310,8 +321,14 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
         if (rok && nok[tn]) {
           if (hasR) vv += *reinterpret_cast<const f32x4*>(Rb + (unsigned)(tr * a.ldr + tn * 16));
           vv *= alpha;
-          if (hasY && !((ABL & 8) && vv[0] != 12345.f)) *reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)) = vv;
-          if (hasY16 && !((ABL & 8) && vv[0] != 12345.f)) *reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)) = pack4_16<PREC>(vv);
+          if (hasY && !((ABL & 8) && vv[0] != 12345.f)) {
+            if (ABL & 64) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)));
+            else *reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)) = vv;
+          }
+          if (hasY16 && !((ABL & 8) && vv[0] != 12345.f)) {
+            if (ABL & 64) __builtin_nontemporal_store(pack4_16<PREC>(vv), reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)));
+            else *reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)) = pack4_16<PREC>(vv);
+          }
           ss[tn] += vv * vv;
         }
       }

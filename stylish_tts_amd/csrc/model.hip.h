@@ -727,6 +727,11 @@ struct Seg {
   int n_utt;
   const int* host;
   const int* dev;
+  // capacity segments: `host` holds UPPER BOUNDS (cumulative capacities; every buffer and grid is sized by them), `dev` the real
+  // offsets, known on the device only (frame_offsets_kernel).  The rows of utterance u are [dev[u], dev[u+1]) - packed, so the
+  // rows in [dev[n_utt], host[n_utt]) are unused.  dev[u] <= host[u] for every u.
+  bool cap = false;
+  const int* rows_dev() const { return cap ? dev + n_utt : nullptr; }  // the real row count, for kernels that walk all rows
   int rows() const { return host[n_utt]; }
   int max_len() const {
     int m = 0;
@@ -742,6 +747,7 @@ inline GemmArgs gemm_args(const Seg& s) {
   a.seg_host = s.host;
   a.n_utt = s.n_utt;
   a.rows_total = s.rows();
+  a.capacity = s.cap;
   a.alpha = 1.0f;
   a.zeros = zero_page();
   return a;
@@ -808,6 +814,7 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   std::vector<int> seg_h(n + 1);
   for (int j = 0; j <= n; ++j) seg_h[j] = (int)(j * pr);
   Seg sp{n, seg_h.data(), segp};
+  sp.cap = s.cap;  // capacity segments: the planes' host offsets (j * pr) are upper bounds of the device ones (j * real groups) too
   GemmArgs a = gemm_args(sp);
   set_seg(a, 0, Xp, kc, 0, wc.planes, 0);
   a.seg[0].w_utt_stride = (long)wc.planes.npad * kc;
@@ -1261,7 +1268,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
           fa.gate = cond; fa.ld_gate = w.ld_gate; fa.gcol0 = w.gcol0; fa.out_acc = w.out_acc; fa.tail = w.tail;
           fa.W3 = L.fused.W3; fa.b3m = L.fused.b3m; fa.b3s = L.fused.b3s; fa.Z = w.Z; fa.ldz = w.ldz; fa.zcol0 = w.zcol0;
           if (w.tail > 1) { fa.W4 = c->flow[f - 1].fused.W4; fa.b4 = c->flow[f - 1].fused.b4; fa.Hpre = w.Hpre; }
-          if (s.n_utt <= kWnSegInline) {
+          if (s.n_utt <= kWnSegInline && !s.cap) {  // (the inlined offsets are the host's: not with capacity segments)
             fa.n_inline = s.n_utt;
             memcpy(fa.seg_inline, s.host, (s.n_utt + 1) * sizeof(int));
           }
@@ -1284,7 +1291,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         fa.gate = cond; fa.ld_gate = w.ld_gate; fa.gcol0 = w.gcol0; fa.out_acc = w.out_acc; fa.tail = w.tail;
         fa.W3 = L.fused.H3; fa.b3m = L.fused.b3m; fa.b3s = L.fused.b3s; fa.Z = w.Z; fa.ldz = w.ldz; fa.zcol0 = w.zcol0;
         if (w.tail > 1) { fa.W4 = c->flow[f - 1].fused.H4; fa.b4 = c->flow[f - 1].fused.b4; fa.Hpre = w.Hpre; }
-        if (s.n_utt <= kWnSegInline) {
+        if (s.n_utt <= kWnSegInline && !s.cap) {
           fa.n_inline = s.n_utt;
           memcpy(fa.seg_inline, s.host, (s.n_utt + 1) * sizeof(int));
         }
@@ -1345,9 +1352,10 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
   STTS_CHECK(ws.ok, "harmonic_stft: workspace too small");
   STTS_CHECK(ld >= kBins && ld <= 64 * ((kBins + 63) / 64), "harmonic_stft: row stride %d outside [%d, %d]", ld, kBins, 64 * ((kBins + 63) / 64));
   STTS_DRY_RETURN(ws);
-  for (int u = 0; u < s.n_utt; ++u)
-    STTS_CHECK((long)(s.host[u + 1] - s.host[u]) * kHop > kNfft / 2, "utterance %d too short for reflect padding (%d frames; need > %d samples)", u,
-               s.host[u + 1] - s.host[u], kNfft / 2);
+  if (!s.cap)  // (capacity segments: pcph_kernel checks the real lengths and raises the device error word 4)
+    for (int u = 0; u < s.n_utt; ++u)
+      STTS_CHECK((long)(s.host[u + 1] - s.host[u]) * kHop > kNfft / 2, "utterance %d too short for reflect padding (%d frames; need > %d samples)", u,
+                 s.host[u + 1] - s.host[u], kNfft / 2);
   STTS_LAUNCH_PROF("pcph_prep_kernel", (size_t)R * 12, pcph_prep_kernel, dim3(s.n_utt), dim3(256), st, pitch, s.dev, prefix, stats);
   STTS_LAUNCH_PROF("pcph_kernel", (size_t)R * kHop * 8, pcph_kernel, dim3(std::min(1024, ceil_div(s.max_len() * kHop, 256)), s.n_utt), dim3(256), st, pitch, s.dev, s.n_utt,
                      prefix, stats, noise, init_phase, batch_scope, sig, c->d_err);
@@ -1360,9 +1368,9 @@ inline int harmonic_stft(stts_ctx* c, hipStream_t st, const Seg& s, const float*
 // stage: vocoder body + iSTFT (models/generator.py:412-433)
 // ------------------------------------------------------------------------------------------------
 inline int ln_launch(hipStream_t st, const float* X, int ldx, int C, long n_rows, const int* row_utt, float eps, int adaptive, int nout,
-                     const LnOut& o0, const LnOut& o1, int act, const LnIn& in = LnIn{}) {
+                     const LnOut& o0, const LnOut& o1, int act, const LnIn& in = LnIn{}, const int* n_rows_dev = nullptr) {
   STTS_LAUNCH_PROF("row_layernorm_kernel", (size_t)n_rows * C * (1 + nout) * 4, row_layernorm_kernel, dim3((unsigned)ceil_div((int)n_rows, 4)), dim3(256), st, X, ldx, C, (int)n_rows, row_utt, eps,
-                     adaptive, nout, o0, o1, act, in);
+                     adaptive, nout, o0, o1, act, in, n_rows_dev);
   STTS_HIP(hipGetLastError());
   return 0;
 }
@@ -1466,7 +1474,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
       STTS_LAUNCH_PROF("dwconv_kernel", (size_t)R * h * 2 * 4, (dwconv_kernel<31>), dim3(ceil_div(h, 64), ceil_div(ml, 64), s.n_utt), dim3(256), st, cur, h, dw, h, h, s.dev, B.dw_wt,
                          B.dw_b, B.K, (int)ACT_NONE);
       LnOut o0{nrm, h, 0, sty, nullptr, lds, B.norm.col0, p16}, o1{};
-      STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE));
+      STTS_TRY(ln_launch(st, dw, h, h, R, row_utt, 1e-6f, 1, 1, o0, o1, ACT_NONE, LnIn{}, s.rows_dev()));
     }
     GemmArgs a = gemm_args(s);
     set_seg(a, 0, nrm, h, 0, B.pw1);
@@ -1491,7 +1499,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
   // two AdaLN heads (eps 1e-5) into columns [0,512) of the head inputs (generator.py:417-423)
   {
     LnOut o0{headA, hc, 0, sty, nullptr, lds, c->head_amp.col0, p16}, o1{headP, hc, 0, sty, nullptr, lds, c->head_phase.col0, p16};
-    STTS_TRY(ln_launch(st, cur, h, h, R, row_utt, 1e-5f, 1, 2, o0, o1, ACT_NONE));
+    STTS_TRY(ln_launch(st, cur, h, h, R, row_utt, 1e-5f, 1, 2, o0, o1, ACT_NONE, LnIn{}, s.rows_dev()));
   }
   {
     GemmArgs a = gemm_args(s);

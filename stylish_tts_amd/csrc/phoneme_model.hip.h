@@ -257,9 +257,9 @@ inline int static_ln(hipStream_t st, const float* X, int ldx, int C, long rows, 
   return ln_launch(st, X, ldx, C, rows, nullptr, eps, 0, 1, o0, o1, act);
 }
 inline int adaptive_ln(hipStream_t st, const float* X, int ldx, int C, long rows, const int* row_utt, float eps, const float* sty, int ld_sty,
-                       int gcol0, float* Y, int ldy) {
+                       int gcol0, float* Y, int ldy, const int* rows_dev = nullptr) {
   LnOut o0{Y, ldy, 0, sty, nullptr, ld_sty, gcol0}, o1{};
-  return ln_launch(st, X, ldx, C, rows, row_utt, eps, 1, 1, o0, o1, ACT_NONE);
+  return ln_launch(st, X, ldx, C, rows, row_utt, eps, 1, 1, o0, o1, ACT_NONE, LnIn{}, rows_dev);
 }
 
 // Conv/Linear (+ residual) followed by a LayerNorm over the channels.  When the launcher cut K over several blocks the
@@ -472,9 +472,9 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
   // compute_cross (pitch_energy_predictor.py:83-102): base = prosody^T @ alignment == gather by the frame->token map
   hipLaunchKernelGGL(frame_token_map_kernel, dim3(sp.n_utt), dim3(256), 0, st, dur, sp.dev, sf.dev, 1, src_row);
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long>(2048, std::max<long>(1, ceil_div((int)(Rf * C / 4), 256)))), dim3(256), 0, st, pros, C,
-                     src_row, base, C, 0, C, (int)Rf);
+                     src_row, base, C, 0, C, (int)Rf, sf.rows_dev());
   hipLaunchKernelGGL(local_token_kernel, dim3(ceil_div(sf.max_len(), 256), sf.n_utt), dim3(256), 0, st, src_row, sf.dev, sp.dev, centre);
-  STTS_TRY(adaptive_ln(st, base, C, C, Rf, row_utt_f, 1e-5f, sty, lds, P.qn.col0, qn, C));
+  STTS_TRY(adaptive_ln(st, base, C, C, Rf, row_utt_f, 1e-5f, sty, lds, P.qn.col0, qn, C, sf.rows_dev()));
   STTS_TRY(adaptive_ln(st, pros, C, C, Rp, row_utt_p, 1e-5f, sty, lds, P.kn.col0, kn, C));
   STTS_TRY(gemm_store(st, sf, qn, C, 0, P.q, q, C, 0));
   STTS_TRY(gemm_store(st, sp, kn, C, 0, P.kv, kv, 2 * C, 0));

@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0,
                                                    float* __restrict__ out, int* __restrict__ err) {
   const int u = blockIdx.y;
   const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
+  // the STFT reflects kNfft / 2 samples at both ends: shorter utterances cannot be padded (torch.stft raises; the host checks this
+  // when it knows the lengths, here for lengths that only exist on the device)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (long)nfr * kHop <= kNfft / 2) atomicMax(err, 4);
   float mnf = stats[2 * u];
   int anyv = stats[2 * u + 1] > 0.5f;
   if (batch_scope) {

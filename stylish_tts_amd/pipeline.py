@@ -3,8 +3,16 @@
 The reference has no packaged inferencer (README roadmap): its callers loop per utterance over
 DurationPredictor → DurationProcessor → ExportModel (``train/test_onnx.py:48-79``, ``train/stage_type.py:483-523``).
 This is that composition for a list of utterances of any lengths in ONE pass: every stage runs on the packed
-sequences (per-utterance semantics, no padding), with a single host read in the middle for the predicted frame counts
-(the same round trip the reference has at ``test_onnx.py:65-66``).
+sequences (per-utterance semantics, no padding).
+
+The reference reads the predicted durations on the host between its two models (``test_onnx.py:65-66``) because the
+alignment matrix must be sized.  Here nothing is read back in the middle: the frame-rate stages run on CAPACITY SEGMENTS
+(include/stylish_hip.h, STTS_SEG_CAPACITY) - every buffer and grid is sized by an upper bound of each utterance's frame
+count, the real offsets are computed on the device from the durations (``stts_frame_offsets``) and the waveforms come out
+packed by the real lengths, which the host reads ONCE, with the audio.  The upper bound is frames-per-token x tokens: it
+starts at ``frames_per_token`` (default 8; the reference's table allows 46 per token, real speech averages 5-6), grows to
+1.25 x the largest ratio seen in earlier calls, and a call whose prediction does not fit (the frame counts read with the audio
+exceed a capacity; the truncated segments kept every kernel in bounds) is repeated with exactly the capacities it asked for.
 """
 from __future__ import annotations
 
@@ -14,16 +22,24 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .runtime import HipModel, Segments
+from .runtime import CapacityOverflow, HipModel, Segments
 from .text import TextCleaner, frame_tokens, to_int16, write_wav
 
 
 class Synthesizer:
     """engine: a HipModel with all components finalized (load_weights(..., which=255))."""
 
-    def __init__(self, engine: HipModel):
+    MAX_FRAMES_PER_TOKEN = 46  # the largest entry of the reference's duration table (train/utils.py:391-393)
+
+    def __init__(self, engine: HipModel, frames_per_token: float = 8.0, adapt: bool = True):
+        """frames_per_token: capacity (mel frames per token) the frame-rate buffers are sized by; with `adapt` it follows what the model
+        predicts from call to call (adapt=False: the same capacities for the same token counts in every call, hence the same launch
+        plans and bit-identical results from call to call)."""
         self.eng = engine
         self.cfg = engine.cfg
+        self._ratio = float(frames_per_token)
+        self._adapt = adapt
+        self.capacity_retries = 0  # calls repeated because a prediction did not fit its capacity
         self.text_cleaner = TextCleaner(self.cfg.symbol) if "symbol" in self.cfg else None
         self._lane = self._new_lane()
         self._lanes: List[dict] = []  # extra lanes of map(): one per concurrent call
@@ -88,7 +104,7 @@ class Synthesizer:
     def __call__(self, token_lists: Sequence[Sequence[int]], noise: Optional[Dict[str, torch.Tensor]] = None, return_details: bool = False):
         return self._run(token_lists, noise, return_details, self._lane)
 
-    host_syncs_per_call = 1  # reads of device data by the host between the duration predictor and the frame path
+    host_syncs_per_call = 0  # reads of device data by the host between the duration predictor and the frame path
 
     def stage_times(self, token_lists, noise=None) -> Dict[str, float]:
         """One call with events between the stages on the caller's stream: milliseconds of the phoneme-rate part (everything up to
@@ -102,10 +118,23 @@ class Synthesizer:
         torch.cuda.synchronize(self.eng.device)
         return dict(phoneme_ms=ev[0].elapsed_time(ev[1]), frame_ms=ev[1].elapsed_time(ev[2]))
 
+    def _capacities(self, L: Sequence[int]) -> List[int]:
+        r = min(self._ratio, float(self.MAX_FRAMES_PER_TOKEN))
+        return [min(self.MAX_FRAMES_PER_TOKEN * n, int(np.ceil(r * n)) + 8) for n in L]
+
     @torch.no_grad()
     def _run(self, token_lists, noise, return_details, lane):
-        eng, dev = self.eng, self.eng.device
         L = [len(t) for t in token_lists]
+        caps = self._capacities(L)
+        while True:
+            try:
+                return self._run_once(token_lists, L, caps, noise, return_details, lane)
+            except CapacityOverflow as e:  # rare: the model predicted more frames than this call's buffers hold - repeat it with what it asked for
+                self.capacity_retries += 1
+                caps = [max(int(n), c) for n, c in zip(e.need, caps)]
+
+    def _run_once(self, token_lists, L, caps, noise, return_details, lane):
+        eng, dev = self.eng, self.eng.device
         toks = torch.tensor([int(v) for t in token_lists for v in t], dtype=torch.int64, device=dev)
         sp = Segments(L, dev)
         main = torch.cuda.current_stream(dev)
@@ -126,14 +155,10 @@ class Synthesizer:
             return e, y
 
         jobs = [lane["pool"].submit(encode, 2, lane["side"][0]), lane["pool"].submit(encode, 1, lane["side"][1])]
-        # 1. durations (DurationPredictor + DurationProcessor.prediction_to_duration)
+        # 1. durations (DurationPredictor + DurationProcessor.prediction_to_duration), then the frame offsets ON THE DEVICE:
+        #    st / st4 are capacity layouts (host = upper bounds, device = the real cumulative frame counts)
         _, dur = eng.duration(sp, toks)
-        csum = torch.cumsum(dur, 0)
-        ends = csum[torch.as_tensor(sp.host[1:].astype(np.int64) - 1, device=dev)]
-        T = torch.diff(ends, prepend=torch.zeros(1, dtype=ends.dtype, device=dev)).cpu().tolist()  # the one host sync
-        T = [int(v) for v in T]
-        st = Segments(T, dev)
-        st4 = st.scaled(4)
+        st, st4, need = eng.frame_offsets(sp, dur, caps)
         (pe_enc, pe_style), (enc, style) = jobs[0].result(), jobs[1].result()
         main.wait_stream(lane["side"][0])
         main.wait_stream(lane["side"][1])
@@ -142,7 +167,7 @@ class Synthesizer:
         # 3b. speech predictor front (length regulator, x4 upsampling)
         asr = eng.length_regulate(sp, st4, dur, 4, enc, self.cfg.inter_dim)
         p4, e4 = eng.upsample4(st, st4, f0), eng.upsample4(st, st4, en)
-        # 4. frame path
+        # 4. frame path.  Explicit noise is indexed by the REAL packed rows (as the outputs are): only its first rows are read.
         R = st4.rows
         if noise is None:
             noise = dict(prior_noise=torch.randn(R, 128, device=dev), src_noise=torch.randn(R * 75, device=dev),
@@ -152,8 +177,20 @@ class Synthesizer:
         audio = eng.frame_path(st4, asr, p4, e4, style, noise["prior_noise"], noise["src_noise"], noise["init_phase"], batch_scope=False)
         if ev:
             ev[2].record(main)
+        # the one host read of the call: status + frame counts, together with the audio
         eng.check_status()
-        waves = [audio[75 * int(st4.host[i]) : 75 * int(st4.host[i + 1])] for i in range(len(L))]
+        T = [int(v) for v in need.cpu().tolist()]
+        if any(t > c for t, c in zip(T, caps)):  # truncated utterances: this call's output is invalid
+            e = CapacityOverflow(f"predicted frames {T} exceed the capacities {list(caps)}")
+            e.need = T
+            raise e
+        # capacity of the next calls: 1.25 x the largest frames-per-token ratio seen so far (monotone, so it settles after the first
+        # calls and equal inputs then get equal capacities, launch plans and results)
+        if self._adapt:
+            self._ratio = min(float(self.MAX_FRAMES_PER_TOKEN), max(self._ratio, 1.25 * max(t / max(n, 1) for t, n in zip(T, L))))
+        off = np.concatenate([[0], np.cumsum(T)]) * (4 * 75)
+        waves = [audio[int(off[i]) : int(off[i + 1])] for i in range(len(L))]
         if return_details:
-            return waves, dict(durations=dur, frames=T, pitch=f0, energy=en, style=style)
+            Tm = int(sum(T))
+            return waves, dict(durations=dur, frames=T, pitch=f0[:Tm], energy=en[:Tm], style=style, capacities=list(caps))
         return waves

@@ -28,24 +28,45 @@ def _stream():
 
 
 class Segments:
-    """Utterance row offsets (host int32 array + device copy)."""
+    """Utterance row offsets (host int32 array + device copy).
 
-    def __init__(self, lengths: Sequence[int], device):
+    capacity=True (``Segments.capacity``): the host array holds UPPER BOUNDS - cumulative capacities that size every buffer and
+    grid - and the device tensor the real offsets, written on the device by ``HipModel.frame_offsets`` (include/stylish_hip.h,
+    STTS_SEG_CAPACITY): no host read of the predicted durations is needed before the frame-rate stages."""
+
+    def __init__(self, lengths: Sequence[int], device, dev: Optional[torch.Tensor] = None, capacity: bool = False):
         lengths = [int(x) for x in lengths]
         self.lengths = lengths
         self.host = np.zeros(len(lengths) + 1, np.int32)
         self.host[1:] = np.cumsum(lengths)
-        self.dev = torch.from_numpy(self.host).to(device)
+        self.dev = dev if dev is not None else torch.from_numpy(self.host).to(device)
         self.n = len(lengths)
         self.rows = int(self.host[-1])
         self.max_len = max(lengths)
+        self.is_capacity = capacity
+
+    @classmethod
+    def capacity(cls, caps: Sequence[int], device) -> "Segments":
+        """Capacity layout: `caps` rows per utterance at most; the device offsets are uninitialised until frame_offsets fills them."""
+        return cls(caps, device, dev=torch.empty(len(caps) + 1, dtype=torch.int32, device=device), capacity=True)
+
+    @property
+    def flags(self) -> int:
+        return 1 if self.is_capacity else 0  # STTS_SEG_CAPACITY
 
     @property
     def host_ptr(self):
         return self.host.ctypes.data_as(C.c_void_p)
 
-    def scaled(self, k: int) -> "Segments":
+    def scaled(self, k: int, dev: Optional[torch.Tensor] = None) -> "Segments":
+        if self.is_capacity:
+            assert dev is not None, "a scaled capacity layout needs its own device offsets"
+            return Segments([x * k for x in self.lengths], self.dev.device, dev=dev, capacity=True)
         return Segments([x * k for x in self.lengths], self.dev.device)
+
+
+class CapacityOverflow(RuntimeError):
+    """An utterance's predicted frame count exceeded the capacity its buffers were sized for (stts_frame_offsets)."""
 
 
 class HipModel:
@@ -108,6 +129,19 @@ class HipModel:
     def check_status(self):
         _lib.check(self.lib.stts_check_status(self.ctx, _stream()))
 
+    def frame_offsets(self, seg_p: Segments, dur: torch.Tensor, caps: Sequence[int]):
+        """Device-side DurationProcessor bookkeeping: -> (mel-rate Segments, vocoder-rate Segments, need) as CAPACITY layouts whose
+        device offsets are the real ones (cumulative predicted frames).  `caps`: mel frames each utterance may have at most.
+        need [n_utt] int32 (device): the frames each utterance asked for; need[u] > caps[u] = overflow: the utterance was truncated
+        to its capacity (every stage stays in bounds) and the call must be repeated with larger capacities (CapacityOverflow is
+        what Synthesizer raises internally when it reads `need` with the audio)."""
+        st = Segments.capacity(caps, self.device)
+        off4 = torch.empty(seg_p.n + 1, dtype=torch.int32, device=self.device)
+        need = torch.empty(seg_p.n, dtype=torch.int32, device=self.device)
+        cap_dev = torch.from_numpy(st.host).to(self.device, non_blocking=True)
+        _lib.check(self.lib.stts_frame_offsets(self.ctx, _stream(), seg_p.n, _ptr(seg_p.dev), _ptr(dur), _ptr(cap_dev), _ptr(st.dev), _ptr(off4), _ptr(need)))
+        return st, st.scaled(4, dev=off4), need
+
     # ------------------------------------------------------------------ workspace
     def workspace(self, seg: Segments) -> torch.Tensor:
         need = int(self.lib.stts_frame_workspace_bytes(self.ctx, seg.rows, seg.n, seg.max_len))
@@ -165,7 +199,7 @@ class HipModel:
         ws = self.workspace(seg)
         _lib.check(self.lib.stts_frame_path(self.ctx, _stream(), seg.n, seg.host_ptr, _ptr(seg.dev), _ptr(asr), asr.shape[1], _ptr(pitch),
                                             _ptr(energy), _ptr(style), _ptr(prior_noise), _ptr(src_noise), _ptr(init_phase), int(batch_scope),
-                                            _ptr(audio), _ptr(ws), ws.numel()))
+                                            _ptr(audio), _ptr(ws), ws.numel(), seg.flags))
         return audio
 
     # ------------------------------------------------------------------ layout bridge + single ops
@@ -272,7 +306,7 @@ class HipModel:
         ws = self._ph_ws(seg_p.rows, seg_t.rows, seg_p.n)
         _lib.check(self.lib.stts_pitch_energy_forward(self.ctx, _stream(), seg_p.n, seg_p.host_ptr, _ptr(seg_p.dev), seg_t.host_ptr, _ptr(seg_t.dev),
                                                       _ptr(dur), _ptr(pe_enc), pe_enc.shape[1], _ptr(pe_style), _ptr(f0), _ptr(en),
-                                                      _ptr(t["prosody"]) if t else None, _ptr(t["cross"]) if t else None, _ptr(ws), ws.numel()))
+                                                      _ptr(t["prosody"]) if t else None, _ptr(t["cross"]) if t else None, _ptr(ws), ws.numel(), seg_t.flags))
         return (f0, en, t) if taps else (f0, en)
 
     def length_regulate(self, seg_p: Segments, seg_f: Segments, dur: torch.Tensor, rep: int, enc: torch.Tensor, C: int):

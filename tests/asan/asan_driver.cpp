@@ -44,16 +44,19 @@ static int frame_case(stts_ctx* c, const std::vector<int>& lens, const char* wha
     return 1;
   }
   auto asr = buf(R * 128), pitch = buf(R), energy = buf(R), style = buf((size_t)n * 64), pn = buf(R * 128), sn = buf(R * 75), ph = buf(1), audio = buf(R * 75);
-  auto x = buf(R * 512), mel = buf(R * 512), hs = buf(R * 1056), hp = buf(R * 1056);
+  auto x = buf(R * 512), mel = buf(R * 512), hs = buf(R * 1088), hp = buf(R * 1088);  // 1088: the spectrum row stride every operand mode accepts (fp32 needs >= 1056, the 16-bit modes 1088)
   const long before = stts_stub_launch_count();
   CK(stts_frame_path(c, nullptr, n, off.data(), off.data(), asr.data(), 128, pitch.data(), energy.data(), style.data(), pn.data(), sn.data(), ph.data(), 0,
-                     audio.data(), ws.data(), wsb));
+                     audio.data(), ws.data(), wsb, 0));
   const long fused = stts_stub_launch_count() - before;
+  // the same call with capacity segments (STTS_SEG_CAPACITY: the host offsets are upper bounds, the device ones - the same array here - real)
+  CK(stts_frame_path(c, nullptr, n, off.data(), off.data(), asr.data(), 128, pitch.data(), energy.data(), style.data(), pn.data(), sn.data(), ph.data(), 0,
+                     audio.data(), ws.data(), wsb, STTS_SEG_CAPACITY));
   // the staged entry points carve the same workspace stage by stage
   CK(stts_decoder_forward(c, nullptr, n, off.data(), off.data(), asr.data(), 128, pitch.data(), energy.data(), style.data(), x.data(), 512, ws.data(), wsb));
   CK(stts_prior_flow_forward(c, nullptr, n, off.data(), off.data(), x.data(), 512, style.data(), pn.data(), mel.data(), 512, nullptr, nullptr, ws.data(), wsb));
-  CK(stts_harmonic_stft(c, nullptr, n, off.data(), off.data(), pitch.data(), sn.data(), ph.data(), 1, nullptr, hs.data(), hp.data(), 1056, ws.data(), wsb));
-  CK(stts_vocoder_forward(c, nullptr, n, off.data(), off.data(), mel.data(), 512, style.data(), hs.data(), hp.data(), 1056, audio.data(), nullptr, nullptr, 0,
+  CK(stts_harmonic_stft(c, nullptr, n, off.data(), off.data(), pitch.data(), sn.data(), ph.data(), 1, nullptr, hs.data(), hp.data(), 1088, ws.data(), wsb));
+  CK(stts_vocoder_forward(c, nullptr, n, off.data(), off.data(), mel.data(), 512, style.data(), hs.data(), hp.data(), 1088, audio.data(), nullptr, nullptr, 0,
                           ws.data(), wsb));
   printf("  %-44s rows %8ld  workspace %8.1f MB  %ld launches per frame-path call\n", what, R, wsb / 1048576.0, fused);
   return 0;
@@ -80,7 +83,13 @@ static int phoneme_case(stts_ctx* c, const std::vector<int>& toks, const std::ve
   }
   CK(stts_duration_forward(c, nullptr, n, to.data(), to.data(), tokens.data(), logits.data(), dur_out.data(), nullptr, nullptr, nullptr, ws.data(), wsb));
   CK(stts_pitch_energy_forward(c, nullptr, n, to.data(), to.data(), fo.data(), fo.data(), dur.data(), mu.data(), 256, sty.data(), f0.data(), en.data(), nullptr,
-                               nullptr, ws.data(), wsb));
+                               nullptr, ws.data(), wsb, 0));
+  CK(stts_pitch_energy_forward(c, nullptr, n, to.data(), to.data(), fo.data(), fo.data(), dur.data(), mu.data(), 256, sty.data(), f0.data(), en.data(), nullptr,
+                               nullptr, ws.data(), wsb, STTS_SEG_CAPACITY));
+  {
+    std::vector<int32_t> offT(n + 1), offT4(n + 1), need(n);
+    CK(stts_frame_offsets(c, nullptr, n, to.data(), dur.data(), fo.data(), offT.data(), offT4.data(), need.data()));
+  }
   CK(stts_length_regulate(c, nullptr, n, dur.data(), to.data(), fo4.data(), 4 * T, 4, mu.data(), 256, 128, enc4.data(), 128, idx.data()));
   CK(stts_upsample4(c, nullptr, n, fo.data(), fo.data(), fo4.data(), f0.data(), up.data()));
   printf("  %-44s tokens %6ld frames %7ld  workspace %8.1f MB\n", what, P, T, wsb / 1048576.0);

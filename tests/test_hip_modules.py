@@ -164,14 +164,15 @@ def test_export_model_end_to_end(mods):
 
 
 def test_synthesizer_map_equals_sequential_calls(mods, weights, cfg):
-    """Synthesizer.map: batches in flight on their own streams / host threads give exactly what one call after the other gives."""
+    """Synthesizer.map: batches in flight on their own streams / host threads give exactly what one call after the other gives
+    (fixed capacities: the launch plans, hence the fp32 summation orders, depend on the sizes the host sees)."""
     from stylish_tts_amd import synth
     from stylish_tts_amd.pipeline import Synthesizer
 
     eng = mods["speech_predictor"].engine
     for m in mods.values():
         m.engine
-    syn = Synthesizer(eng)
+    syn = Synthesizer(eng, frames_per_token=24, adapt=False)
     batches = [[synth.tokens(f"map.{j}.{i}", 1, 6 + 3 * ((i + j) % 4), 178)[0].tolist() for i in range(1 + j % 3)] for j in range(7)]
     noises = []
     for j, b in enumerate(batches):
@@ -270,7 +271,7 @@ def test_synthesizer_soak_random_batches(mods):
         waves, det = syn(toks, return_details=True)
         assert len(waves) == B
         for w, T in zip(waves, det["frames"]):
-            assert w.numel() == 300 * T and bool(torch.isfinite(w).all()) and float(w.abs().max()) < 1.0
+            assert w.numel() == 300 * T and bool(torch.isfinite(w).all()) and float(w.abs().max()) <= 1.0  # tanh: [-1, 1] in fp32
 
 
 def test_conv_stft_module_shim(cfg):

@@ -190,11 +190,16 @@ def test_cfg3_chain_b64_bf16_vs_rounded_oracle(cfg, weights):
         O.OPERAND_ROUND = None
     print(f"\n[cfg3: B={B} x {P} tokens, bf16 operands; {sum(T)} mel frames = {sum(T) / 80:.0f} s of audio] vs the rounded oracle:",
           {k: f"{v:.1e}" for k, v in errs.items()})
-    # Synthesizer == this staged composition (same kernels, same noise)
+    # Synthesizer (no host read between the duration predictor and the frame path: capacity segments) == this staged composition with
+    # the exact offsets read on the host: same kernels, same noise, the same integer frame counts; the launch plans (tile shapes, split-K
+    # factors) follow the sizes the host sees, so fp32 sums may be ordered differently and flip individual bf16 operand roundings
     syn = Synthesizer(eng)
     waves, det = syn([t.tolist() for t in toks], noise=noise, return_details=True)
-    assert det["frames"] == T
-    assert torch.equal(torch.cat(waves), audio)
+    assert det["frames"] == T and syn.host_syncs_per_call == 0
+    assert torch.equal(det["durations"], dur)
+    gap = float((torch.cat(waves) - audio).abs().max())
+    print(f"[cfg3] Synthesizer (capacity segments, {syn.capacity_retries} capacity retries) vs the staged composition: waveform max-abs difference {gap:.2e}")
+    assert gap < CFG3_TOL["audio_rounded"]
     eng.close()
     for k, v in errs.items():
         assert v < CFG3_TOL[k], (k, v, errs)

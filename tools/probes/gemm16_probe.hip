@@ -153,6 +153,7 @@ static int run(int n_utt, int rows_per_utt, int cin, int cout, int k, bool check
         case 3: return launch_conv_gemm16<3>(st, a, npad, n_utt);
         case 7: return launch_conv_gemm16<7>(st, a, npad, n_utt);
         case 32: return launch_conv_gemm16<32>(st, a, npad, n_utt);
+        case 64: return launch_conv_gemm16<64>(st, a, npad, n_utt);
         default: return launch_conv_gemm16<0>(st, a, npad, n_utt);
       }
     };
@@ -161,7 +162,7 @@ static int run(int n_utt, int rows_per_utt, int cin, int cout, int k, bool check
     std::vector<std::vector<float>> t(n_abl);
     for (int r = 0; r < rounds; ++r)
       for (int v = 0; v < n_abl; ++v) {
-        const int which = n_abl == 2 ? (v == 0 ? 0 : 32) : abl[v];
+        const int which = n_abl == 2 ? (v == 0 ? 0 : 64) : abl[v];
         STTS_TRY(go(which));
         STTS_HIP(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) STTS_TRY(go(which));
@@ -174,7 +175,7 @@ static int run(int n_utt, int rows_per_utt, int cin, int cout, int k, bool check
     for (int v = 0; v < n_abl; ++v) {
       std::sort(t[v].begin(), t[v].end());
       const float mn = t[v][0], md = t[v][rounds / 2];
-      printf("%-11s %-13s rows=%ld cin=%d cout=%d k=%d epi=%d: min %7.1f us %7.1f TFLOP/s | median %7.1f us %7.1f TFLOP/s\n", name, abl_name[n_abl == 2 ? (v == 0 ? 0 : 8) : v], R, cin, cout, k,
+      printf("%-11s %-13s rows=%ld cin=%d cout=%d k=%d epi=%d: min %7.1f us %7.1f TFLOP/s | median %7.1f us %7.1f TFLOP/s\n", name, (n_abl == 2 && v == 1) ? "nt stores" : abl_name[v], R, cin, cout, k,
              epi, 1e3 * mn, flops / (mn * 1e-3) * 1e-12, 1e3 * md, flops / (md * 1e-3) * 1e-12);
     }
   }
