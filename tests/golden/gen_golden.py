@@ -397,6 +397,33 @@ def main():
     save("mrf_block", x=xm, style=style, y=ym, **meta)
 
 
+def frame_path_3s_more():
+    """Two more distinct 3-s utterances through the reference's decoder -> prior / reverse flow -> vocoder (frame_path_3s_b / _c): with
+    frame_path_3s they make a batch of DISTINCT utterances at the benchmarked size (tests/test_hip_benchmarked_path.py)."""
+    mc = load_model_config_yaml(open(os.path.join(REF_SRC, "stylish_tts/train/config/model.yml")))
+    cfg = load_model_config()
+    meta = dict(torch_version=torch.__version__, seed=SEED)
+    sp = load_synth(SpeechPredictor(mc), "speech_predictor", cfg)
+    CutTape.stft = sp.generator.stft
+    T4b = 960
+    for tag in ("b", "c"):
+        asr_b = t(synth.normal(f"g3{tag}.asr", (1, 128, T4b)))
+        pitch_3 = t(synth.pitch_curve(f"g3{tag}.pitch", 1, T4b))
+        energy_3 = t(synth.uniform(f"g3{tag}.energy", (1, T4b)) * 2.0 + 2.0)
+        style_3 = t(synth.normal(f"g3{tag}.style", (1, 64)) * 0.7)
+        nz3 = synth.path_noise(f"frame960{tag}", 1, T4b)
+        # the initial phase is ONE scalar per call (models/generator.py:306 draws rand(1, 1) for the whole batch): the three goldens share
+        # frame_path_3s's, so that they can be batched into one call
+        nz3["init_phase"] = synth.path_noise("frame960", 1, T4b)["init_phase"]
+        with Replay(randn=[nz3["src_noise"]], rand=[nz3["init_phase"]], randn_like=[nz3["prior_noise"]]), CutTape() as cut:
+            xd, _ = sp.decoder(asr_b, pitch_3, energy_3, style_3)
+            z, mean, logstd = sp.prior_encoder(xd)
+            z2, _, _ = sp.flow(z, mean, logstd, 1, style_3.unsqueeze(-1), reverse=True)
+            mel3 = sp.post_flow(z2.mT).mT
+            pred3 = sp.generator(mel=mel3, style=style_3, pitch=pitch_3, energy=energy_3)
+        save(f"frame_path_3s_{tag}", audio=pred3.audio, mel_probe=mel3[:, ::64, ::16], x_probe=xd[:, ::64, ::16], **cut.hints(), **meta)
+
+
 def text_golden():
     """Tokeniser and wav-writer vectors (lib/text_utils.py:8-41, train/test_onnx.py:49-53,79-90)."""
     import io, json
@@ -569,7 +596,9 @@ def conv_stft_golden():
 
 
 if __name__ == "__main__":
-    if "--only-conv-stft" in sys.argv:
+    if "--only-3s-more" in sys.argv:
+        frame_path_3s_more()
+    elif "--only-conv-stft" in sys.argv:
         conv_stft_golden()
     elif "--only-narrow" in sys.argv:
         narrow_golden()
@@ -586,3 +615,4 @@ if __name__ == "__main__":
         cfm_decoder_golden()
         conv_stft_golden()
         narrow_golden()
+        frame_path_3s_more()

@@ -7,7 +7,11 @@ AdaIN apply pass instead of the folded affine (`run_adain_block`, rows > 4 096),
   (1) with the REFERENCE's own waveform: the `frame_path_3s` golden tiled to B = 8 (every utterance of the batch must
       reproduce the golden's audio), with the atan2 branch ties adopted the reference's way between the STFT and the
       vocoder stage (oracle.align_branch; the number of adopted bins and the raw, un-adopted error are printed);
-  (2) with the numpy oracle on utterance 0 of bench.py's own synthetic cfg2 inputs;
+  (2) with THREE distinct reference waveforms batched as eight distinct rows of utterances (frame_path_3s, _b, _c: a fault at an
+      utterance boundary inside a 128-row tile cannot hide behind identical neighbours), and the CONDITIONAL part of the parity
+      claim itself: the raw product (no adoption) may differ from the reference only inside the vocoder's receptive field of an
+      adopted bin - everywhere else it meets the 1e-3 bar on its own;
+  (3) with the numpy oracle on utterances 0, 3 and 7 of bench.py's own synthetic cfg2 inputs;
 
 and the fused entry point `stts_frame_path` (what bench.py calls) must be bit-identical to the staged calls.
 Tolerance: waveform sample-wise max-abs < 1e-3, intermediates 2e-4 of their max-abs.
@@ -105,6 +109,60 @@ def test_cfg2_batch8_reproduces_the_reference_waveform(hip):
           f"raw product path (no adoption): {raw.max():.2e} over all samples, {late:.2e} after frame 64, "
           f"{(frames > 1e-3).sum() // B} of {T4} frames per utterance above 1e-3")
     assert errs.max() < 1e-3, errs
+
+
+# frames of audio an adopted har_phase bin can reach: phase_prior_conv k7 (3) + ConvNeXt depthwise 31 / 15 / 7 / 3 (15 + 7 + 3 + 1) + output
+# convs k7 (3) = 32 spectral frames, + 8 frames of overlap-add (a 1 200-sample window spans 16 hops of 75) = 40.  (GRN's norm over
+# time couples all frames of an utterance, at the 1e-6 level: far inside the bar.)
+RECEPTIVE_FRAMES = 40
+
+
+def test_cfg2_distinct_utterances_and_the_scope_of_the_branch_adoption(hip):
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+
+    gold = {"": load_golden("frame_path_3s"), "b": load_golden("frame_path_3s_b"), "c": load_golden("frame_path_3s_c")}
+    order = ["", "b", "c", "b", "", "c", "c", "b"]  # eight utterances, neighbours always differ
+    B, T4 = len(order), 960
+    s = segs([T4] * B)
+    cat = lambda f: np.concatenate([f(tag) for tag in order])  # noqa: E731
+    asr = dev(cat(lambda tg: synth.normal(f"g3{tg}.asr", (1, 128, T4))[0].T))
+    pitch = dev(cat(lambda tg: synth.pitch_curve(f"g3{tg}.pitch", 1, T4)[0]))
+    energy = dev(cat(lambda tg: (synth.uniform(f"g3{tg}.energy", (1, T4)) * 2.0 + 2.0).astype(np.float32)[0]))
+    style = dev(cat(lambda tg: (synth.normal(f"g3{tg}.style", (1, 64)) * 0.7).astype(np.float32)))
+    pn = dev(cat(lambda tg: synth.path_noise(f"frame960{tg}", 1, T4)["prior_noise"][0].T))
+    sn = dev(cat(lambda tg: synth.path_noise(f"frame960{tg}", 1, T4)["src_noise"].reshape(-1)))
+    ph0 = dev(synth.path_noise("frame960", 1, T4)["init_phase"].reshape(-1))  # one scalar per call: the goldens share it
+    x = hip.decoder(s, asr, pitch, energy, style)
+    mel = hip.prior_flow(s, x, style, pn)
+    spec, phase = hip.harmonic_stft(s, pitch, sn, ph0, batch_scope=False)  # harmonic count per utterance, as the reference's B = 1 runs
+    ph = phase.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
+    sp_ = spec.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
+    fixed_rows = np.zeros((B * T4, phase.shape[1]), np.float32)
+    touched = np.zeros((B, T4), bool)  # frames with at least one adopted bin
+    for b, tg in enumerate(order):
+        g = gold[tg]
+        fx, nb = O.align_branch(ph[b : b + 1], (g["cut_idx"].astype(np.int64), g["cut_phase"].astype(np.float32)), sp_[b : b + 1], return_bad=True)
+        assert nb == 0, (b, tg, nb)
+        touched[b] = (fx[0] != ph[b]).any(axis=0)
+        fixed_rows[b * T4 : (b + 1) * T4, :1025] = fx[0].T
+    adopted = hip.vocoder(s, mel, style, spec, dev(fixed_rows)).cpu().numpy().reshape(B, -1)
+    raw = hip.frame_path(s, asr, pitch, energy, style, pn, sn, ph0, batch_scope=False).cpu().numpy().reshape(B, -1)
+    worst, outside_max, n_inside = 0.0, 0.0, 0
+    for b, tg in enumerate(order):
+        ref = gold[tg]["audio"].reshape(-1)
+        worst = max(worst, float(np.abs(adopted[b] - ref).max()))
+        # receptive field of the adopted bins, in audio frames
+        reach = np.zeros(T4, bool)
+        for f in np.nonzero(touched[b])[0]:
+            reach[max(0, f - RECEPTIVE_FRAMES) : f + RECEPTIVE_FRAMES + 1] = True
+        err = np.abs(raw[b] - ref).reshape(T4, 75).max(axis=1)
+        n_inside += int(reach.sum())
+        outside_max = max(outside_max, float(err[~reach].max()) if (~reach).any() else 0.0)
+        assert (err[~reach] < 1e-3).all(), (b, tg, float(err[~reach].max()), int(np.argmax(np.where(reach, 0, err))))
+    print(f"\n[cfg2, 8 distinct utterances vs 3 reference goldens] with adoption: max-abs {worst:.2e}; raw product: {n_inside // B} of {T4} frames per utterance lie "
+          f"within {RECEPTIVE_FRAMES} frames of an adopted bin (any error allowed there), everywhere else max-abs {outside_max:.2e} < 1e-3")
+    assert worst < 1e-3, worst
 
 
 def test_bench_inputs_match_the_oracle(hip, weights):
