@@ -115,6 +115,9 @@ def test_cfg2_batch8_reproduces_the_reference_waveform(hip):
 # convs k7 (3) = 32 spectral frames, + 8 frames of overlap-add (a 1 200-sample window spans 16 hops of 75) = 40.  (GRN's norm over
 # time couples all frames of an utterance, at the 1e-6 level: far inside the bar.)
 RECEPTIVE_FRAMES = 40
+# an adoption counts when it moves a frame's phases by this much in total (a branch flip is 2 pi; the phase of a ~zero-magnitude bin is
+# rounding noise and can move by anything, but the prior conv's weights make a whole radian matter and a thousandth not)
+ADOPTION_RAD = float(os.environ.get("STTS_ADOPTION_RAD", "1.0"))
 
 
 def test_cfg2_distinct_utterances_and_the_scope_of_the_branch_adoption(hip):
@@ -139,29 +142,31 @@ def test_cfg2_distinct_utterances_and_the_scope_of_the_branch_adoption(hip):
     ph = phase.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
     sp_ = spec.cpu().numpy()[:, :1025].reshape(B, T4, 1025).transpose(0, 2, 1)
     fixed_rows = np.zeros((B * T4, phase.shape[1]), np.float32)
-    touched = np.zeros((B, T4), bool)  # frames with at least one adopted bin
+    moved = np.zeros((B, T4))  # per frame: total |phase change| of the adoption, radians (a branch flip moves a bin by 2 pi)
     for b, tg in enumerate(order):
         g = gold[tg]
         fx, nb = O.align_branch(ph[b : b + 1], (g["cut_idx"].astype(np.int64), g["cut_phase"].astype(np.float32)), sp_[b : b + 1], return_bad=True)
         assert nb == 0, (b, tg, nb)
-        touched[b] = (fx[0] != ph[b]).any(axis=0)
+        moved[b] = np.abs(fx[0].astype(np.float64) - ph[b]).sum(axis=0)
         fixed_rows[b * T4 : (b + 1) * T4, :1025] = fx[0].T
     adopted = hip.vocoder(s, mel, style, spec, dev(fixed_rows)).cpu().numpy().reshape(B, -1)
     raw = hip.frame_path(s, asr, pitch, energy, style, pn, sn, ph0, batch_scope=False).cpu().numpy().reshape(B, -1)
-    worst, outside_max, n_inside = 0.0, 0.0, 0
+    worst, outside_max, n_inside, n_bad = 0.0, 0.0, 0, 0
     for b, tg in enumerate(order):
         ref = gold[tg]["audio"].reshape(-1)
         worst = max(worst, float(np.abs(adopted[b] - ref).max()))
-        # receptive field of the adopted bins, in audio frames
+        # audio frames within reach of a frame whose adoption moved the phases by at least ADOPTION_RAD in total
         reach = np.zeros(T4, bool)
-        for f in np.nonzero(touched[b])[0]:
+        for f in np.nonzero(moved[b] >= ADOPTION_RAD)[0]:
             reach[max(0, f - RECEPTIVE_FRAMES) : f + RECEPTIVE_FRAMES + 1] = True
         err = np.abs(raw[b] - ref).reshape(T4, 75).max(axis=1)
         n_inside += int(reach.sum())
-        outside_max = max(outside_max, float(err[~reach].max()) if (~reach).any() else 0.0)
+        n_bad += int((err >= 1e-3).sum())
+        outside_max = max(outside_max, float(err[~reach].max()))
+        assert (~reach).sum() > T4 // 2, (b, tg, int(reach.sum()))  # the claim is not vacuous: most of the utterance is out of reach
         assert (err[~reach] < 1e-3).all(), (b, tg, float(err[~reach].max()), int(np.argmax(np.where(reach, 0, err))))
-    print(f"\n[cfg2, 8 distinct utterances vs 3 reference goldens] with adoption: max-abs {worst:.2e}; raw product: {n_inside // B} of {T4} frames per utterance lie "
-          f"within {RECEPTIVE_FRAMES} frames of an adopted bin (any error allowed there), everywhere else max-abs {outside_max:.2e} < 1e-3")
+    print(f"\n[cfg2, 8 distinct utterances vs 3 reference goldens] with adoption: max-abs {worst:.2e}; raw product: {n_bad // B} of {T4} frames per utterance differ by "
+          f">= 1e-3, all of them among the {n_inside // B} frames within {RECEPTIVE_FRAMES} frames of an adoption of >= {ADOPTION_RAD} rad; everywhere else max-abs {outside_max:.2e}")
     assert worst < 1e-3, worst
 
 
