@@ -18,6 +18,7 @@
 #include "wn_layer_small.hip.h"
 #include "wn_fused.hip.h"
 #include "wn_fused16.hip.h"
+#include "wn_block16.hip.h"
 #include "winograd.hip.h"
 
 namespace stts {
@@ -91,6 +92,7 @@ struct WnFusedW {
   // 16-bit operand modes (wn_fused16_kernel): the same matrices as 16-bit fragments, conv in direct (tap-major) form
   unsigned short* H1[4] = {};
   unsigned short* H2[4] = {};
+  unsigned short* H2b[4] = {};  // res_skip in wn_block16_kernel's tile order (wave w: res 32w.., skip 32w..; layer 3: skip only)
   unsigned short* H3 = nullptr;
   unsigned short* H4 = nullptr;
   bool ready = false;    // fp32 fragments packed
@@ -464,6 +466,13 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
         return wr.data.data() + ((size_t)16 * nct * wv + 16 * t + col) * C;
       }, f32_to_bf16, f32_to_f16);
       STTS_TRY(dev_upload(c, f2, &o->H2[i]));
+      // wn_block16_kernel: wave w owns the res rows AND the skip rows [32 w, 32 w + 32) (tiles: res, res + 16, skip, skip + 16; layer 3: skip, skip + 16)
+      const int nctb = n_rs == 2 * C ? 4 : 2;
+      const std::vector<unsigned short> f2b = pack_fragments16(c->prec, kWnWaves, C / 32, nctb, [&](int wv, int t, int col) {
+        const int row = n_rs == 2 * C ? (t < 2 ? 32 * wv + 16 * t + col : C + 32 * wv + 16 * (t - 2) + col) : 32 * wv + 16 * t + col;
+        return wr.data.data() + (size_t)row * C;
+      }, f32_to_bf16, f32_to_f16);
+      STTS_TRY(dev_upload(c, f2b, &o->H2b[i]));
     }
     STTS_TRY(dev_upload(c, br->data, &o->b2[i]));
   }
@@ -1184,11 +1193,14 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     long b128 = 0;
     for (int u = 0; u < s.n_utt; ++u) b128 += ceil_div(s.host[u + 1] - s.host[u], 128);
     fused16_rt = b128 >= 384 ? 8 : 4;
+    // at least ~0.75 chip rounds of 128-row blocks: one launch per coupling layer with h and `out` on chip (wn_block16.hip.h)
+    if (b128 >= 192) fused16_rt = 16;
     const int force = getenv("STTS_WN_RT") ? atoi(getenv("STTS_WN_RT")) : 0;  // tests / tools
-    if (force == 4 || force == 8) fused16_rt = force;
+    if (force == 4 || force == 8 || force == 16) fused16_rt = force;
     if (force == -1) fused16_rt = 0;  // the staged kernel
   }
   auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
+  float* blk_in = hf;  // wn_block16_kernel: the coupling layer's h_0 (ping-pongs between hf and hf2)
   for (int f = 7; f >= 0; --f) {
     const FlowLayerW& L = c->flow[f];
     const int p = f & 1;
@@ -1224,6 +1236,40 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       set_seg(a, 0, z, fh, p * half, L.pre);
       a.N = fh; a.bias = L.pre.bias; a.Y = hf; a.ldy = fh;
       STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, L.pre.npad, s.n_utt, ml));
+    }
+    if (fused16_rt == 16) {
+      // ---- one launch for the whole coupling layer (16-bit modes, large batches): reads h_0 = pre(z0) from `blk_in`, writes the next
+      // coupling layer's h_0 to the other buffer (neighbouring blocks still read their halo rows of `blk_in`)
+      WnBlock16Args ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.Hin = blk_in; ba.seg_off = s.dev; ba.gate = cond; ba.ld_gate = c->flow_style.ld();
+      double flops = 0;
+      for (int i = 0; i < 4; ++i) {
+        ba.W1[i] = L.fused.H1[i]; ba.b1[i] = L.fused.b1[i]; ba.W2[i] = L.fused.H2b[i]; ba.b2[i] = L.fused.b2[i];
+        ba.gcol0[i] = L.cond_col0 + i * 2 * fh;
+        flops += 2.0 * (double)R * 2 * fh * 5 * fh + 2.0 * (double)R * (double)L.rs[i].N * fh;
+      }
+      ba.tail = f > 0 ? 2 : 1;
+      ba.W3 = L.fused.H3; ba.b3m = L.fused.b3m; ba.b3s = L.fused.b3s; ba.Z = z; ba.ldz = fh; ba.zcol0 = (1 - p) * half;
+      flops += 2.0 * (double)R * fh * fh;
+      float* blk_out = blk_in == hf ? hf2 : hf;
+      if (f > 0) {
+        ba.W4 = c->flow[f - 1].fused.H4; ba.b4 = c->flow[f - 1].fused.b4; ba.Hpre = blk_out;
+        flops += 2.0 * (double)R * fh * half;
+      }
+      GemmProfiler& prof = gemm_profiler();
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (prof.on) {
+        e0 = prof.next();
+        e1 = prof.next();
+        prof.add("wn_block16_kernel", 0, flops, flops, 0.0);
+      }
+      const dim3 bgrid(ceil_div(ml, kWnBlockRows), s.n_utt);
+      if (c->prec == PREC_BF16) STTS_LAUNCH_TIMED((wn_block16_kernel<PREC_BF16>), bgrid, dim3(64 * kWnWaves), st, e0, e1, ba);
+      else STTS_LAUNCH_TIMED((wn_block16_kernel<PREC_F16>), bgrid, dim3(64 * kWnWaves), st, e0, e1, ba);
+      blk_in = blk_out;
+      STTS_HIP(hipGetLastError());
+      continue;
     }
     float* hcur = hf;
     float* hnext = hf2;

@@ -217,8 +217,8 @@ def test_phoneme_stages_stay_fp32_in_16bit_modes(cfg, weights, prec):
 
 @pytest.mark.parametrize("prec,tol", [("bf16", 2e-2), ("f16", 3e-3)])
 def test_flow_16bit_fused_kernel_variants(cfg, weights, rounded_oracle, prec, tol, monkeypatch):
-    """The reverse flow in the 16-bit operand modes: wn_fused16_kernel on 64- and 128-row blocks (picked by batch size in
-    production, forced here) and the staged wn_layer_kernel share their rounding points (h entering LDS, gated activations,
+    """The reverse flow in the 16-bit operand modes: wn_fused16_kernel on 64- and 128-row blocks, wn_block16_kernel (one launch per coupling
+    layer, 128-row blocks + 2 x 8 halo rows; all picked by batch size in production, forced here) and the staged wn_layer_kernel share their rounding points (h entering LDS, gated activations,
     `out` before post, the coupled half before pre), so all three must sit within the mode's noise of the oracle whose
     contraction operands are rounded at those points, on lengths that leave partial blocks and one-row utterances.
     Tolerance: relative to max |z|; 8 coupling layers x 4 WaveNet layers of operand roundings (2^-9 bf16, 2^-11 fp16)."""
@@ -228,7 +228,7 @@ def test_flow_16bit_fused_kernel_variants(cfg, weights, rounded_oracle, prec, to
     hip = HipModel(cfg, 0, precision=prec)
     hip.load_weights({"speech_predictor": weights["speech_predictor"]}, which=7)
     w = weights["speech_predictor"]
-    lens = [129, 1, 70, 260, 2, 63]
+    lens = [129, 1, 70, 260, 2, 63, 128, 400]
     s = segs(lens)
     xs = [synth.normal(f"wn16.x{i}", (1, 512, L)) for i, L in enumerate(lens)]
     st = (synth.normal("wn16.s", (len(lens), 64)) * 0.7).astype(np.float32)
@@ -240,7 +240,7 @@ def test_flow_16bit_fused_kernel_variants(cfg, weights, rounded_oracle, prec, to
         z, _, _ = O.prior_encoder(xs[i], ns[i], w)
         refs.append(O.flow_reverse(z, st[i : i + 1, :, None], w))
     got = {}
-    for rt in ("4", "8", "-1"):
+    for rt in ("4", "8", "16", "-1"):
         monkeypatch.setenv("STTS_WN_RT", rt)
         _, _, zf = hip.prior_flow(s, cat(xs), dev(st), cat(ns), return_z=True)
         got[rt] = zf.cpu().numpy()
@@ -252,7 +252,8 @@ def test_flow_16bit_fused_kernel_variants(cfg, weights, rounded_oracle, prec, to
             ref = refs[i]
             e = max(e, float(np.abs(zf[s.host[i] : s.host[i + 1], :128].T[None] - ref).max() / np.abs(ref).max()))
         errs[rt] = e
-    print(f"\n[{prec} flow vs rounded oracle] 64-row blocks {errs['4']:.1e}, 128-row blocks {errs['8']:.1e}, staged kernel {errs['-1']:.1e}")
-    assert np.isfinite(got["4"]).all() and np.isfinite(got["8"]).all()
+    print(f"\n[{prec} flow vs rounded oracle] 64-row blocks {errs['4']:.1e}, 128-row blocks {errs['8']:.1e}, one launch per coupling layer {errs['16']:.1e}, "
+          f"staged kernel {errs['-1']:.1e}")
+    assert np.isfinite(got["4"]).all() and np.isfinite(got["8"]).all() and np.isfinite(got["16"]).all()
     for rt, e in errs.items():
         assert e < tol, (prec, rt, errs)
