@@ -393,68 +393,71 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ X
 // ---------------------------------------------------------------------------------------------
 // ConvNeXt front half in one launch (models/generator.py:449-462): depthwise conv along time + adaptive LayerNorm over channels,
 //   y[r] = LN_C(dw(x)[r]) * (1 + gamma_u) + beta_u,
-// for C <= 512 and the kernel sizes the generator uses (template K).  A block owns 16 rows x all channels: the rows + halo are
-// staged in LDS once, every thread pulls the 16 + K - 1 inputs of its channels into registers ONCE (the two-kernel form reads
-// K values from LDS per output: at K = 31 that, not HBM, is what bounds it), the conv results replace the staged rows, and each
-// wave normalises four of them - the intermediate [rows, C] tensor (one write + one read, and one of two launches) disappears.
-// Per element the arithmetic and its order are those of dwconv_kernel followed by row_layernorm_kernel (taps in order;
-// lane-strided float4 sums, then the wave reduction).
+// for C <= 512 and the kernel sizes the generator uses (template K).  A block owns ROWS rows x all channels.  Every thread pulls
+// the ROWS + K - 1 inputs of its channel straight from global memory into a register window (one coalesced 256-byte row segment
+// per wave and row, all of them in flight at once; the halo rows of neighbouring blocks come out of L2), the conv results go to
+// LDS (ROWS x C floats: 32 KB at 16 rows, so five blocks share a CU - staging the INPUT rows + halo there, as round 2 did,
+// took 94 KB at K = 31 = one block of four waves per CU, and the kernel ran at 0.19 of the HBM rate), and each wave normalises
+// its share of the rows - the intermediate [rows, C] tensor (one write + one read, and one of two launches) never reaches HBM.
+// ROWS = 32 for the long kernels halves their halo re-reads.  Per element the arithmetic and its order are those of
+// dwconv_kernel followed by row_layernorm_kernel (taps in order; lane-strided float4 sums, then the wave reduction).
 // ---------------------------------------------------------------------------------------------
-constexpr int kDwLnRows = 16, kDwLnMaxC = 512;
-template <int K>
+constexpr int kDwLnMaxC = 512;
+template <int K, int ROWS>
 __global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
                                                         const float* __restrict__ Wt, const float* __restrict__ bias, float eps,
                                                         const float* __restrict__ style, int ld_style, int gcol0, float* __restrict__ Y, int ldy,
                                                         int prec16) {
-  constexpr int NR = kDwLnRows + K - 1;
-  __shared__ float tile[NR * kDwLnMaxC];
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-descriptor type exists on the device side only)
+  constexpr int NR = ROWS + K - 1;
+  __shared__ float tile[ROWS * kDwLnMaxC];
   const int u = blockIdx.y;
   const int lo = seg_off[u], hi = seg_off[u + 1];
-  const int r0 = lo + blockIdx.x * kDwLnRows;
+  const int r0 = lo + blockIdx.x * ROWS;
   if (r0 >= hi) return;
   constexpr int pad = (K - 1) / 2;
   const int c4n = C / 4;
-  for (int i = threadIdx.x; i < NR * c4n; i += 256) {
-    const int rr = i / c4n, c4 = (i % c4n) * 4;
-    const int g = r0 - pad + rr;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g >= lo && g < hi) v = *reinterpret_cast<const float4*>(X + (long)g * ldx + c4);
-    *reinterpret_cast<float4*>(&tile[rr * C + c4]) = v;
-  }
-  __syncthreads();
-  // depthwise conv: thread = channels tid, tid + 256 (C <= 512), all 16 rows, inputs held in a register window
-  float acc[2][kDwLnRows];
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (long)lo * ldx), 0, ((hi - lo - 1) * ldx + C) * 4, 0x00020000);
+  // depthwise conv: thread = channels tid, tid + 256 (C <= 512), all ROWS rows, inputs held in a register window
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int c = threadIdx.x + 256 * h;
     if (c < C) {
       float win[NR];
+      // rows outside the utterance (the conv's zero padding) are out-of-range offsets of the utterance's buffer descriptor: the hardware
+      // returns zeros, the NR loads carry no clamp, select or branch and are all in flight together
 #pragma unroll
-      for (int i = 0; i < NR; ++i) win[i] = tile[i * C + c];
+      for (int i = 0; i < NR; ++i) win[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ((r0 - lo - pad + i) * ldx + c) * 4, 0, 0));
       const float bv = bias[c];
+      float acc[ROWS];
 #pragma unroll
-      for (int i = 0; i < kDwLnRows; ++i) acc[h][i] = bv;
+      for (int i = 0; i < ROWS; ++i) acc[i] = bv;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float w = Wt[(long)k * C + c];
 #pragma unroll
-        for (int i = 0; i < kDwLnRows; ++i) acc[h][i] += w * win[i + k];
+        for (int i = 0; i < ROWS; ++i) acc[i] += w * win[i + k];
       }
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) tile[i * C + c] = acc[i];
     }
-  }
-  __syncthreads();  // every input has been read: the conv results take the place of the first 16 rows
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = threadIdx.x + 256 * h;
-    if (c < C)
-#pragma unroll
-      for (int i = 0; i < kDwLnRows; ++i) tile[i * C + c] = acc[h][i];
   }
   __syncthreads();
   // LayerNorm: wave w takes rows w, w + 4, ...
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* gp0 = style + (long)u * ld_style + gcol0;
-  for (int i = wv; i < kDwLnRows; i += 4) {
+  float4 gg[2], bb[2];
+#pragma unroll
+  for (int q2 = 0; q2 < 2; ++q2) {
+    const int q = lane + 64 * q2;
+    gg[q2] = bb[q2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < c4n) {
+      gg[q2] = *reinterpret_cast<const float4*>(gp0 + q * 4);
+      bb[q2] = *reinterpret_cast<const float4*>(gp0 + C + q * 4);
+      gg[q2].x += 1.f; gg[q2].y += 1.f; gg[q2].z += 1.f; gg[q2].w += 1.f;
+    }
+  }
+  for (int i = wv; i < ROWS; i += 4) {
     const int r = r0 + i;
     if (r >= hi) break;
     float4 v[2];
@@ -478,14 +481,13 @@ __global__ void __launch_bounds__(256) dwconv_ln_kernel(const float* __restrict_
     for (int q2 = 0; q2 < 2; ++q2) {
       const int q = lane + 64 * q2;
       if (q < c4n) {
-        float4 g = *reinterpret_cast<const float4*>(gp0 + q * 4);
-        const float4 b = *reinterpret_cast<const float4*>(gp0 + C + q * 4);
-        g.x += 1.f; g.y += 1.f; g.z += 1.f; g.w += 1.f;
+        const float4 g = gg[q2], b = bb[q2];
         store4(Y, (long)r * ldy + q * 4, (v[q2].x - mean) * rstd * g.x + b.x, (v[q2].y - mean) * rstd * g.y + b.y, (v[q2].z - mean) * rstd * g.z + b.z,
                (v[q2].w - mean) * rstd * g.w + b.w, prec16);
       }
     }
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,20 +647,21 @@ __global__ void __launch_bounds__(256) decoder_front_kernel(FrontArgs a, const i
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < a.c_asr) {
       o = *reinterpret_cast<const float4*>(a.asr + (long)r * a.ld_asr + c4);
-    } else if (c4 == a.c_asr) {
-      const float pm = r > lo ? a.pitch[r - 1] : 0.f, pp = r + 1 < hi ? a.pitch[r + 1] : 0.f;
-      const float em = r > lo ? a.energy[r - 1] : 0.f, ep = r + 1 < hi ? a.energy[r + 1] : 0.f;
-      const float f0 = a.wf[0] * pm + a.wf[1] * a.pitch[r] + a.wf[2] * pp + a.bf;
-      const float nn = a.wn[0] * em + a.wn[1] * a.energy[r] + a.wn[2] * ep + a.bn;
-      o.x = f0;
-      o.y = nn;
+    } else {
+      // the quads behind the phoneme encoding: quad 0 carries (F0, N, 0, 0); the same quads fill the tail [F0 | N | 0..] of both concat
+      // buffers with 16-byte stores (one lane writing the ~30 zeros of a row one by one had made this kernel 10x slower than its traffic)
+      const int k = (c4 - a.c_asr) / 4, nk = (a.ld_enc - a.c_asr) / 4;
+      if (k == 0) {
+        const float pm = r > lo ? a.pitch[r - 1] : 0.f, pp = r + 1 < hi ? a.pitch[r + 1] : 0.f;
+        const float em = r > lo ? a.energy[r - 1] : 0.f, ep = r + 1 < hi ? a.energy[r + 1] : 0.f;
+        o.x = a.wf[0] * pm + a.wf[1] * a.pitch[r] + a.wf[2] * pp + a.bf;
+        o.y = a.wn[0] * em + a.wn[1] * a.energy[r] + a.wn[2] * ep + a.bn;
+      }
       const int cc = a.c_hidden + a.c_res;  // 576: F0, N columns of the concat buffers; zero the tail
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        float* p = (w == 0 ? a.xa : a.xb) + (long)r * a.ld_x + cc;
-        p[0] = f0;
-        p[1] = nn;
-        for (int k = 2; k < a.ld_x - cc; ++k) p[k] = 0.f;
+      for (int kk = k; cc + 4 * kk < a.ld_x; kk += nk) {
+        const float4 t = kk == 0 ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(a.xa + (long)r * a.ld_x + cc + 4 * kk) = t;
+        *reinterpret_cast<float4*>(a.xb + (long)r * a.ld_x + cc + 4 * kk) = t;
       }
     }
     *reinterpret_cast<float4*>(a.enc_in + (long)r * a.ld_enc + c4) = o;
@@ -712,8 +715,11 @@ struct ChanConvSet {
   float* Y;
 };
 constexpr int kChanRows = 8, kChanTaps = 7;
+template <int X16>
 __global__ void __launch_bounds__(256) single_channel_conv_kernel(ChanConvSet s0, ChanConvSet s1, int ldx, int C, const int* __restrict__ seg_off, int ntaps,
-                                                                  int ldy, int ycol, int x16) {
+                                                                  int ldy, int ycol) {
+  constexpr int x16 = X16;  // (compile time: with a run-time switch inside the unrolled row loop hipcc branched around every load and waited for each)
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-descriptor type exists on the device side only)
   const ChanConvSet& S = blockIdx.y == 0 ? s0 : s1;
   const int u = blockIdx.z;
   const int lo = seg_off[u], hi = seg_off[u + 1];
@@ -721,6 +727,9 @@ __global__ void __launch_bounds__(256) single_channel_conv_kernel(ChanConvSet s0
   const int r0 = lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * kChanRows;
   if (r0 >= hi) return;
   const int pad = (ntaps - 1) / 2, nv = C / 4;
+  // (rows a wave with fewer taps than kChanTaps does not need are loaded too: their weights are zero)
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(S.X) + (long)lo * ldx * (x16 ? 2 : 4)), 0, ((hi - lo - 1) * ldx + C) * (x16 ? 2 : 4), 0x00020000);
   float acc[kChanRows];
 #pragma unroll
   for (int i = 0; i < kChanRows; ++i) acc[i] = 0.f;
@@ -728,16 +737,31 @@ __global__ void __launch_bounds__(256) single_channel_conv_kernel(ChanConvSet s0
     float4 wt[kChanTaps];
 #pragma unroll
     for (int t = 0; t < kChanTaps; ++t) wt[t] = t < ntaps ? *reinterpret_cast<const float4*>(S.w + (long)t * C + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // all input rows of this channel group are requested before the first is used; rows outside the utterance (the conv's zero
+    // padding) are out-of-range offsets of the utterance's buffer descriptor and come back as zeros (no clamp, select or branch)
+    float4 a[kChanRows + kChanTaps - 1];
 #pragma unroll
     for (int j = 0; j < kChanRows + kChanTaps - 1; ++j) {
-      const int g = r0 + j - pad;
-      if (j >= kChanRows + ntaps - 1 || g < lo || g >= hi) continue;
-      const float4 a = x16 ? load4_16(reinterpret_cast<const unsigned short*>(S.X), (long)g * ldx + q * 4, x16)
-                           : *reinterpret_cast<const float4*>(S.X + (long)g * ldx + q * 4);
+      const int off = (r0 - lo - pad + j) * ldx + q * 4;  // elements
+      if constexpr (X16 != 0) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, off * 2, 0, 0);
+        if constexpr (X16 == PREC_BF16) a[j] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+        else {
+          const f16x4_t h = __builtin_bit_cast(f16x4_t, v);
+          a[j] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
+      } else {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, off * 4, 0, 0);
+        a[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kChanRows + kChanTaps - 1; ++j) {
 #pragma unroll
       for (int t = 0; t < kChanTaps; ++t) {
         const int i = j - t;  // output row r0 + i takes input row r0 + i + t - pad = g
-        if (i >= 0 && i < kChanRows) acc[i] += a.x * wt[t].x + a.y * wt[t].y + a.z * wt[t].z + a.w * wt[t].w;
+        if (i >= 0 && i < kChanRows) acc[i] += a[j].x * wt[t].x + a[j].y * wt[t].y + a[j].z * wt[t].z + a[j].w * wt[t].w;
       }
     }
   }
@@ -746,6 +770,7 @@ __global__ void __launch_bounds__(256) single_channel_conv_kernel(ChanConvSet s0
     const float v = wave_sum(acc[i]);
     if (lane == 0 && r0 + i < hi) S.Y[(long)(r0 + i) * ldy + ycol] = v + S.bias;
   }
+#endif
 }
 
 __global__ void fill_kernel(float* p, long n, float v) {

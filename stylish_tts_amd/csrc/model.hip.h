@@ -519,8 +519,8 @@ inline int finalize_frame(stts_ctx* c, int which) {
   // channel sizes come from the model config (lib/config_loader.py:369-414); what the kernels need: 16-byte rows and column
   // offsets (multiples of 32 for the concatenated widths) and the generator reading the decoder's width
   STTS_CHECK(d.style_dim > 0 && d.style_dim % 4 == 0 && d.inter_dim > 0 && d.inter_dim % 4 == 0, "style_dim / inter_dim must be multiples of 4");
-  STTS_CHECK(d.dec_hidden > 0 && d.dec_hidden % 32 == 0 && d.dec_residual >= 0 && d.dec_residual % 2 == 0,
-             "decoder.hidden_dim must be a multiple of 32 (the flow runs on hidden_dim / 4 channels split in two halves), residual_dim even");
+  STTS_CHECK(d.dec_hidden > 0 && d.dec_hidden % 32 == 0 && d.dec_residual >= 0 && d.dec_residual % 4 == 0,
+             "decoder.hidden_dim must be a multiple of 32 (the flow runs on hidden_dim / 4 channels split in two halves), residual_dim a multiple of 4 (16-byte columns)");
   STTS_CHECK(d.gen_input == d.dec_hidden, "generator.input_dim (%d) must equal decoder.hidden_dim (%d): post_flow feeds the generator", d.gen_input, d.dec_hidden);
   STTS_CHECK(d.gen_hidden > 0 && d.gen_hidden % 32 == 0 && d.gen_inter > 0 && d.gen_inter % 32 == 0,
              "generator.hidden_dim / conv_intermediate_dim must be multiples of 32");
@@ -1508,9 +1508,10 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     const ConvNextW& B = c->cnx[i];
     if (h <= kDwLnMaxC && h % 4 == 0 && (B.K == 3 || B.K == 7 || B.K == 15 || B.K == 31)) {
       // depthwise conv + adaptive LayerNorm in one launch (the [rows, h] intermediate never reaches HBM)
-      const dim3 fg(ceil_div(ml, kDwLnRows), s.n_utt);
+      // (32-row blocks for the long kernels - half the halo re-reads, two blocks per CU - measured no faster at B = 64: 64 vs 58 us)
+      const dim3 fg(ceil_div(ml, 16), s.n_utt);
       const size_t fb = (size_t)R * h * (4 + (p16 ? 2 : 4));
-#define STTS_DWLN(KK) STTS_LAUNCH_PROF("dwconv_ln_kernel", fb, dwconv_ln_kernel<KK>, fg, dim3(256), st, cur, h, h, s.dev, B.dw_wt, B.dw_b, 1e-6f, sty, lds, B.norm.col0, nrm, h, p16)
+#define STTS_DWLN(KK) STTS_LAUNCH_PROF("dwconv_ln_kernel", fb, (dwconv_ln_kernel<KK, 16>), fg, dim3(256), st, cur, h, h, s.dev, B.dw_wt, B.dw_b, 1e-6f, sty, lds, B.norm.col0, nrm, h, p16)
       if (B.K == 3) STTS_DWLN(3);
       else if (B.K == 7) STTS_DWLN(7);
       else if (B.K == 15) STTS_DWLN(15);
@@ -1563,8 +1564,11 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     const int kk = c->amp_out.ntaps;
     STTS_CHECK(kk <= kChanTaps, "output conv kernel size %d > %d", kk, kChanTaps);
     const ChanConvSet sa{headA, c->nyq_w[0], c->nyq_b[0], la}, sp{headP, c->nyq_w[1], c->nyq_b[1], ph};
-    STTS_LAUNCH_PROF("single_channel_conv_kernel", (size_t)2 * R * (hc * (p16 ? 2 : 4) + 4), single_channel_conv_kernel,
-                     dim3((unsigned)ceil_div(ml, 4 * kChanRows), 2, s.n_utt), dim3(256), st, sa, sp, hc, hc, s.dev, kk, ldl, kBins - 1, p16);
+    const dim3 cg((unsigned)ceil_div(ml, 4 * kChanRows), 2, s.n_utt);
+    const size_t cb = (size_t)2 * R * (hc * (p16 ? 2 : 4) + 4);
+    if (p16 == PREC_BF16) STTS_LAUNCH_PROF("single_channel_conv_kernel", cb, single_channel_conv_kernel<PREC_BF16>, cg, dim3(256), st, sa, sp, hc, hc, s.dev, kk, ldl, kBins - 1);
+    else if (p16 == PREC_F16) STTS_LAUNCH_PROF("single_channel_conv_kernel", cb, single_channel_conv_kernel<PREC_F16>, cg, dim3(256), st, sa, sp, hc, hc, s.dev, kk, ldl, kBins - 1);
+    else STTS_LAUNCH_PROF("single_channel_conv_kernel", cb, single_channel_conv_kernel<0>, cg, dim3(256), st, sa, sp, hc, hc, s.dev, kk, ldl, kBins - 1);
   }
   STTS_LAUNCH_PROF("istft_frames_kernel", (size_t)R * 2 * kBins * 4, istft_frames_kernel, dim3((ml + 1 + kFftWaves - 1) / kFftWaves, s.n_utt), dim3(64 * kFftWaves), st, la, ph, ldl, s.dev, c->hann, c->twiddle64, yw);
   STTS_LAUNCH_PROF("istft_ola_kernel", (size_t)R * kHop * 4, istft_ola_kernel, dim3(std::min(1024, ceil_div(ml * kHop, 256)), s.n_utt), dim3(256), st, yw, s.dev, c->hann, audio);

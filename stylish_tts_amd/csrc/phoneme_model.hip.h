@@ -495,8 +495,8 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
       cur = bufs[i & 1];
     }
     const ChanConvSet cs{cur, br == 0 ? P.f0_w : P.n_w, br == 0 ? P.f0_b : P.n_b, br == 0 ? f0 : nrg};
-    hipLaunchKernelGGL(single_channel_conv_kernel, dim3((unsigned)ceil_div(sf.max_len(), 4 * kChanRows), 1, sf.n_utt), dim3(256), 0, st, cs, cs, C, C, sf.dev, 1,
-                       1, 0, 0);
+    hipLaunchKernelGGL(single_channel_conv_kernel<0>, dim3((unsigned)ceil_div(sf.max_len(), 4 * kChanRows), 1, sf.n_utt), dim3(256), 0, st, cs, cs, C, C, sf.dev, 1,
+                       1, 0);
   }
   STTS_HIP(hipGetLastError());
   return 0;

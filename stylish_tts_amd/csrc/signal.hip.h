@@ -78,10 +78,15 @@ __global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0,
   if (blockIdx.x == 0 && threadIdx.x == 0 && (long)nfr * kHop <= kNfft / 2) atomicMax(err, 4);
   float mnf = stats[2 * u];
   int anyv = stats[2 * u + 1] > 0.5f;
-  if (batch_scope) {
-    for (int v = 0; v < n_utt; ++v) {
+  if (batch_scope) {  // minimum / any over the call's utterances: lanes take utterances, one wave reduction (every thread looping over all of them was half of this kernel at B = 64)
+    for (int v = threadIdx.x & 63; v < n_utt; v += 64) {
       mnf = fminf(mnf, stats[2 * v]);
       anyv |= stats[2 * v + 1] > 0.5f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mnf = fminf(mnf, __shfl_xor(mnf, o, 64));
+      anyv |= __shfl_xor(anyv, o, 64);
     }
   }
   int K = 0;
