@@ -94,6 +94,7 @@ TEST_SIGNATURES = {
     "stts_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _I]),
     "stts_op_conv1d": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I]),
     "stts_op_adain_block": (_I, [_P, _P, C.c_char_p, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _SZ]),
+    "stts_op_attention": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I]),
 }
 
 _lib = None

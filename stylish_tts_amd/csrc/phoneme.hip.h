@@ -137,6 +137,137 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same attention on the matrix cores, for heads of 64 channels (the flow-matching decoder's XUT blocks: 8 heads x 64, 240-800
+// frames; models/xut/attention.py) - flash-style: a block = 128 queries of one (utterance, head), one wave per 32 queries, the keys /
+// values stream through LDS in blocks of 32 (double buffered, one barrier per block), softmax is kept as a running maximum and sum
+// per query (the exact softmax of attention_kernel up to fp32 rounding: ~1e-7 relative).  v_mfma_f32_32x32x2_f32, fp32 throughout.
+// Both products are taken TRANSPOSED so that a lane owns one query:
+//   S^T[key][q] = K[key][:] . Q[q][:]   A = K block from LDS, B = the wave's Q tile held in 32 registers (lane: query l & 31, channels 2 s + (l >> 5))
+//   O^T[ch][q] += V^T[ch][key] P^T[key][q]   A = V block from LDS, B = exp(S^T - max) - the accumulator registers of the first product, as they are:
+//     register i of a lane holds key kappa(i, h) = 8 (i >> 2) + 4 h + (i & 3), and a sum over keys may visit them in any order, so k-step i
+//     of the second product simply uses key kappa(i, h) for both operands.
+// Per-query max / sum / rescale are per-lane scalars (+ one exchange with lane ^ 32, which holds the other 16 keys of the block).
+// LDS: K rows are stored with channel index c ^ (2 key) (a lane's read K[l & 31][2 s + h] then hits 64 distinct banks), V rows with
+// c ^ (32 ((key >> 2) & 1)) (the two half-waves read different keys of the same 32 channels).
+// ---------------------------------------------------------------------------------------------
+constexpr int kAttnMfmaKc = 64, kAttnMfmaQ = 128;
+__global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
+                                                             int kcol0, const float* __restrict__ V, int ldv, int vcol0, float* __restrict__ O, int ldo,
+                                                             const int* __restrict__ q_off, const int* __restrict__ k_off,
+                                                             const int* __restrict__ band_centre, int window, float scale) {
+  constexpr int KC = kAttnMfmaKc;
+  __shared__ f32x4 Ks[2][32 * KC / 4], Vs[2][32 * KC / 4];
+  const int u = blockIdx.z, h = blockIdx.y;
+  const int qlo = q_off[u], nq = q_off[u + 1] - qlo;
+  const int klo = k_off[u], nk = k_off[u + 1] - klo;
+  if ((int)blockIdx.x * kAttnMfmaQ >= nq) return;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int q0 = blockIdx.x * kAttnMfmaQ + 32 * w;  // this wave's queries (waves beyond the utterance's end compute on its last query and store nothing)
+  const int ql = min(q0 + l31, nq - 1);
+  float qf[KC / 2];
+  {
+    const float* qp = Q + (long)(qlo + ql) * ldq + qcol0 + h * KC + lh;
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) qf[s] = qp[2 * s];
+  }
+  const int centre = band_centre ? band_centre[qlo + ql] : 0;
+  f32x16 o[KC / 32];
+#pragma unroll
+  for (int t = 0; t < KC / 32; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const int nkb = (nk + 31) / 32;
+  // staging: thread -> (key r, float4 group g) of the 32 x 64 block, two of each matrix per thread
+  f32x4 kreg[2], vreg[2];
+  auto gfetch = [&](int kb) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + 256 * e, r = idx >> 4, g = idx & 15;
+      const int j = kb * 32 + r;
+      const bool ok = j < nk;
+      const long row = klo + min(j, nk - 1);
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(K + row * ldk + kcol0 + h * KC + 4 * g);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(V + row * ldv + vcol0 + h * KC + 4 * g);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      kreg[e] = ok ? kv : z;
+      vreg[e] = ok ? vv : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + 256 * e, r = idx >> 4, g = idx & 15;
+      const f32x4 kv = kreg[e];
+      const f32x4 ks = (r & 1) ? f32x4{kv.z, kv.w, kv.x, kv.y} : kv;  // channel index ^ (2 r): group g ^ (r >> 1), pairs swapped for odd keys
+      Ks[buf][r * (KC / 4) + (g ^ (r >> 1))] = ks;
+      Vs[buf][r * (KC / 4) + (g ^ (8 * ((r >> 2) & 1)))] = vreg[e];
+    }
+  };
+  gfetch(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int buf = kb & 1;
+    lstore(buf);
+    if (kb + 1 < nkb) gfetch(kb + 1);
+    __syncthreads();
+    const float* kl = reinterpret_cast<const float*>(Ks[buf]);
+    const float* vl = reinterpret_cast<const float*>(Vs[buf]);
+    // ---- S^T = K Q^T
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kl[l31 * KC + 2 * (s ^ l31) + lh], qf[s], sacc, 0, 0, 0);
+    // ---- scores of query l31 against keys kappa(i, lh): scale, band, validity; running softmax
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = kb * 32 + 8 * (i >> 2) + 4 * lh + (i & 3);
+      float v = sacc[i] * scale;
+      if (band_centre && j >= centre - window && j <= centre + window) v += -1e4f;
+      if (j >= nk) v = -INFINITY;
+      sacc[i] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(m, mx);
+    const float resc = expf(m - mnew);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sacc[i] = expf(sacc[i] - mnew);
+      psum += sacc[i];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    lsum = lsum * resc + psum;
+    m = mnew;
+#pragma unroll
+    for (int t = 0; t < KC / 32; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] *= resc;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int t = 0; t < KC / 32; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = 8 * (i >> 2) + 4 * lh + (i & 3);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[key * KC + ((32 * t + l31) ^ (32 * lh))], sacc[i], o[t], 0, 0, 0);
+      }
+  }
+  if (q0 + l31 < nq) {
+    const float inv = 1.0f / lsum;
+    float* op = O + (long)(qlo + q0 + l31) * ldo + h * KC + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < KC / 32; ++t)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const f32x4 v = {o[t][4 * i4] * inv, o[t][4 * i4 + 1] * inv, o[t][4 * i4 + 2] * inv, o[t][4 * i4 + 3] * inv};
+        *reinterpret_cast<f32x4*>(op + 32 * t + 8 * i4) = v;  // channels 32 t + 8 i4 + 4 lh + (0..3)
+      }
+  }
+}
+
 // Y[row][col0 + c] = style[u][c] for every row of utterance u (ProsodyEncoder concat, models/prosody_encoder.py:67-69,80)
 __global__ void __launch_bounds__(256) broadcast_style_kernel(const float* __restrict__ style, int ld_style, int C, float* __restrict__ Y, int ldy,
                                                               int col0, const int* __restrict__ seg_off) {

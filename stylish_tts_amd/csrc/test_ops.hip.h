@@ -102,6 +102,17 @@ int stts_op_adain_block(stts_ctx* c, void* stream, const char* prefix, int n_utt
   API_END
 }
 
+int stts_op_attention(void* stream, int n_utt, const int32_t* q_off_host, const int32_t* q_off_dev, const int32_t* k_off_host,
+                      const int32_t* k_off_dev, const float* q, const float* k, const float* v, float* o, int heads, int kc,
+                      const int32_t* band_centre, int window, int kernel) {
+  API_BEGIN
+  STTS_CHECK(n_utt > 0 && q_off_host && q_off_dev && k_off_host && k_off_dev && q && k && v && o && heads > 0, "null / empty argument");
+  Seg sq{n_utt, q_off_host, q_off_dev}, sk{n_utt, k_off_host, k_off_dev};
+  const int ld = heads * kc;
+  return run_attention((hipStream_t)stream, sq, sk, q, ld, 0, k, ld, 0, v, ld, 0, o, ld, heads, kc, band_centre, window, kernel);
+  API_END
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------ kernel microbench

@@ -233,6 +233,13 @@ class HipModel:
                                                 cout, _ptr(style), _ptr(y), cout, _ptr(ws), ws.numel()))
         return y
 
+    def op_attention(self, seg_q: Segments, seg_k: Segments, q, k, v, heads: int, kc: int, band_centre=None, window: int = 0, kernel: int = 0):
+        """Packed multi-head attention (test surface): q [q rows, heads * kc], k / v [k rows, heads * kc] -> [q rows, heads * kc]."""
+        o = self._f32(seg_q.rows, heads * kc)
+        _lib.check(self.lib.stts_op_attention(_stream(), seg_q.n, seg_q.host_ptr, _ptr(seg_q.dev), seg_k.host_ptr, _ptr(seg_k.dev), _ptr(q), _ptr(k), _ptr(v),
+                                              _ptr(o), heads, kc, None if band_centre is None else _ptr(band_centre), window, kernel))
+        return o
+
     def op_mrf_block(self, prefix: str, seg: Segments, x, channels, kernel, style):
         y = self._f32(seg.rows, channels)
         ws = self.workspace(seg)

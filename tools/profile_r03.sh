@@ -1,0 +1,33 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): one bench JSON + one `rocprofv3 --kernel-trace --stats` summary per number README / DESIGN quote.
+#   cfg2        bench.py (the bench line: B = 8 x 3 s fp32; roofline, in-run --pmc traffic, cpu_baseline, legs)
+#   bf16_b64    --batch 64 --precision bf16 (cfg3-shaped frame path)       f16_16x10s  --batch 16 --mel-frames 800 --precision f16 (cfg5-shaped)
+#   b1          --batch 1 (latency)                                        cfm / full_chain: tools/cfm_bench.py, tools/full_chain_bench.py
+# tools/kstats.py turns <name>_kernel_stats.csv into the per-kernel tables under profiles/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_r03
+rm -rf "$O" && mkdir -p "$O"
+export TMPDIR=/tmp
+trace() {  # trace NAME script args...: kernel stats of `python3 script args`
+  local name=$1; shift
+  (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$O/${name}_trace" -o t --output-format csv -- python3 "$R/$1" "${@:2}" > "$O/${name}_trace.log" 2>&1)
+  local rc=$?
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[profile] $name trace timed out: stopping" >&2; exit $rc; fi
+  cp "$O/${name}_trace"/*/*kernel_stats.csv "$O/${name}_kernel_stats.csv" 2>/dev/null || cp "$O/${name}_trace"/*kernel_stats.csv "$O/${name}_kernel_stats.csv" 2>/dev/null
+  rm -rf "$O/${name}_trace"
+  echo "[profile] $name done (rc $rc)" >&2
+}
+cd "$R"
+timeout -k 10 500 python3 bench.py > "$O/cfg2_bench.json" 2> "$O/cfg2_bench.err" || echo "[profile] cfg2 bench rc $?" >&2
+trace cfg2 bench.py --no-cpu-baseline --no-traffic --no-legs
+for cfgline in "bf16_b64 --batch 64 --precision bf16" "f16_16x10s --batch 16 --mel-frames 800 --precision f16" "b1 --batch 1"; do
+  set -- $cfgline; name=$1; shift
+  timeout -k 10 200 python3 bench.py "$@" --no-cpu-baseline --no-traffic --no-legs > "$O/${name}_bench.json" 2> "$O/${name}_bench.err"
+  trace "$name" bench.py "$@" --no-cpu-baseline --no-traffic --no-legs
+done
+timeout -k 10 200 python3 tools/cfm_bench.py > "$O/cfm_bench.txt" 2>&1
+trace cfm tools/cfm_bench.py
+timeout -k 10 200 python3 tools/full_chain_bench.py > "$O/full_chain_bench.txt" 2>&1
+trace full_chain tools/full_chain_bench.py
+ls -la "$O"
