@@ -138,26 +138,30 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same attention on the matrix cores, for heads of 64 channels (the flow-matching decoder's XUT blocks: 8 heads x 64, 240-800
-// frames; models/xut/attention.py) - flash-style: a block = 128 queries of one (utterance, head), one wave per 32 queries, the keys /
-// values stream through LDS in blocks of 32 (double buffered, one barrier per block), softmax is kept as a running maximum and sum
-// per query (the exact softmax of attention_kernel up to fp32 rounding: ~1e-7 relative).  v_mfma_f32_32x32x2_f32, fp32 throughout.
-// Both products are taken TRANSPOSED so that a lane owns one query:
-//   S^T[key][q] = K[key][:] . Q[q][:]   A = K block from LDS, B = the wave's Q tile held in 32 registers (lane: query l & 31, channels 2 s + (l >> 5))
+// The same attention on the matrix cores, for heads of KC = 32 / 64 / 96 / 128 channels (the text encoders: 2 heads x 96; the
+// flow-matching decoder's XUT blocks: heads of 64, 240-800 frames, models/xut/attention.py) - flash-style: a block = 128 queries of one
+// (utterance, head), one wave per 32 queries, the keys / values stream through LDS in blocks of 32 (double buffered, one barrier per
+// block), softmax is kept as a running maximum and sum per query (the exact softmax of attention_kernel up to fp32 rounding: ~1e-7
+// relative), any number of keys.  v_mfma_f32_32x32x2_f32, fp32 throughout.  Both products are taken TRANSPOSED so that a lane owns one query:
+//   S^T[key][q] = K[key][:] . Q[q][:]   A = K block from LDS, B = the wave's Q tile held in KC / 2 registers (lane: query l & 31, channels 2 s + (l >> 5))
 //   O^T[ch][q] += V^T[ch][key] P^T[key][q]   A = V block from LDS, B = exp(S^T - max) - the accumulator registers of the first product, as they are:
 //     register i of a lane holds key kappa(i, h) = 8 (i >> 2) + 4 h + (i & 3), and a sum over keys may visit them in any order, so k-step i
 //     of the second product simply uses key kappa(i, h) for both operands.
 // Per-query max / sum / rescale are per-lane scalars (+ one exchange with lane ^ 32, which holds the other 16 keys of the block).
-// LDS: K rows are stored with channel index c ^ (2 key) (a lane's read K[l & 31][2 s + h] then hits 64 distinct banks), V rows with
-// c ^ (32 ((key >> 2) & 1)) (the two half-waves read different keys of the same 32 channels).
+// LDS: K rows have a stride of KC + 2 floats (a lane's read K[l & 31][2 s + h] then hits 64 distinct banks: (KC + 2) mod 64 is 2 or 34),
+// V rows KC + 8 (the two half-waves read keys 4 rows apart: 4 (KC + 8) = 32 mod 64, opposite bank halves).
 // ---------------------------------------------------------------------------------------------
-constexpr int kAttnMfmaKc = 64, kAttnMfmaQ = 128;
+constexpr int kAttnMfmaQ = 128;
+inline bool attn_mfma_kc(int kc) { return kc == 32 || kc == 64 || kc == 96 || kc == 128; }
+template <int KC>
 __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
                                                              int kcol0, const float* __restrict__ V, int ldv, int vcol0, float* __restrict__ O, int ldo,
                                                              const int* __restrict__ q_off, const int* __restrict__ k_off,
                                                              const int* __restrict__ band_centre, int window, float scale) {
-  constexpr int KC = kAttnMfmaKc;
-  __shared__ f32x4 Ks[2][32 * KC / 4], Vs[2][32 * KC / 4];
+  static_assert(KC % 32 == 0 && KC <= 128, "head size");
+  constexpr int KS = KC + 2, VS = KC + 8, G = KC / 4, NE = KC / 32;  // row strides (floats), float4 groups per row, staged float4 per thread and matrix
+  __shared__ float Ks[2][32 * KS];
+  __shared__ f32x4 Vs[2][32 * VS / 4];
   const int u = blockIdx.z, h = blockIdx.y;
   const int qlo = q_off[u], nq = q_off[u + 1] - qlo;
   const int klo = k_off[u], nk = k_off[u + 1] - klo;
@@ -179,12 +183,12 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float m = -INFINITY, lsum = 0.f;
   const int nkb = (nk + 31) / 32;
-  // staging: thread -> (key r, float4 group g) of the 32 x 64 block, two of each matrix per thread
-  f32x4 kreg[2], vreg[2];
+  // staging: thread -> (key r, float4 group g) of the 32 x KC block, NE of each matrix per thread
+  f32x4 kreg[NE], vreg[NE];
   auto gfetch = [&](int kb) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int idx = tid + 256 * e, r = idx >> 4, g = idx & 15;
+    for (int e = 0; e < NE; ++e) {
+      const int idx = tid + 256 * e, r = idx / G, g = idx % G;
       const int j = kb * 32 + r;
       const bool ok = j < nk;
       const long row = klo + min(j, nk - 1);
@@ -197,12 +201,12 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int idx = tid + 256 * e, r = idx >> 4, g = idx & 15;
-      const f32x4 kv = kreg[e];
-      const f32x4 ks = (r & 1) ? f32x4{kv.z, kv.w, kv.x, kv.y} : kv;  // channel index ^ (2 r): group g ^ (r >> 1), pairs swapped for odd keys
-      Ks[buf][r * (KC / 4) + (g ^ (r >> 1))] = ks;
-      Vs[buf][r * (KC / 4) + (g ^ (8 * ((r >> 2) & 1)))] = vreg[e];
+    for (int e = 0; e < NE; ++e) {
+      const int idx = tid + 256 * e, r = idx / G, g = idx % G;
+      float2* kd = reinterpret_cast<float2*>(&Ks[buf][r * KS + 4 * g]);  // (rows are 8-byte aligned: KS is even)
+      kd[0] = make_float2(kreg[e].x, kreg[e].y);
+      kd[1] = make_float2(kreg[e].z, kreg[e].w);
+      Vs[buf][r * (VS / 4) + g] = vreg[e];
     }
   };
   gfetch(0);
@@ -211,14 +215,14 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
     lstore(buf);
     if (kb + 1 < nkb) gfetch(kb + 1);
     __syncthreads();
-    const float* kl = reinterpret_cast<const float*>(Ks[buf]);
-    const float* vl = reinterpret_cast<const float*>(Vs[buf]);
+    const float* kl = Ks[buf] + l31 * KS + lh;
+    const float* vl = reinterpret_cast<const float*>(Vs[buf]) + l31;
     // ---- S^T = K Q^T
     f32x16 sacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < KC / 2; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kl[l31 * KC + 2 * (s ^ l31) + lh], qf[s], sacc, 0, 0, 0);
+    for (int s = 0; s < KC / 2; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kl[2 * s], qf[s], sacc, 0, 0, 0);
     // ---- scores of query l31 against keys kappa(i, lh): scale, band, validity; running softmax
     float mx = -INFINITY;
 #pragma unroll
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = 8 * (i >> 2) + 4 * lh + (i & 3);
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[key * KC + ((32 * t + l31) ^ (32 * lh))], sacc[i], o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[key * VS + 32 * t], sacc[i], o[t], 0, 0, 0);
       }
   }
   if (q0 + l31 < nq) {

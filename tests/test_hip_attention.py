@@ -115,12 +115,26 @@ def test_matrix_core_attention_beyond_1024_keys(hip):
         hip.op_attention(segs(lens), segs(lens), dev(q), dev(k), dev(v), heads, kc, kernel=1)
 
 
+@pytest.mark.parametrize("kc", [32, 96, 128])
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_other_matrix_core_head_sizes(hip, kc, kernel):
+    """Heads of 32 / 96 / 128 channels (the text encoders run 2 x 96) on both kernels."""
+    heads = 2
+    q_lens, k_lens = [50, 130, 7, 257], [50, 130, 40, 100]
+    q, k, v = make(f"att.kc{kc}", q_lens, k_lens, heads, kc, spread=1.5)
+    want = reference(q, k, v, q_lens, k_lens, heads, kc)
+    got = hip.op_attention(segs(q_lens), segs(k_lens), dev(q), dev(k), dev(v), heads, kc, kernel=kernel).cpu().numpy()
+    err = np.abs(got - want).max() / np.abs(want).max()
+    print(f"\n[attention kc {kc} kernel {kernel}] max-abs err {err:.1e}")
+    assert np.isfinite(got).all() and err < 5e-6, (kc, kernel, err)
+
+
 def test_other_head_sizes_stay_on_the_wave_kernel(hip):
-    heads, kc = 2, 96
+    heads, kc = 2, 48
     lens = [130, 40]
-    q, k, v = make("att.kc96", lens, lens, heads, kc)
+    q, k, v = make("att.kc48", lens, lens, heads, kc)
     want = reference(q, k, v, lens, lens, heads, kc)
     got = hip.op_attention(segs(lens), segs(lens), dev(q), dev(k), dev(v), heads, kc).cpu().numpy()
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-6
-    with pytest.raises(RuntimeError, match="matrix-core kernel needs heads of 64"):
+    with pytest.raises(RuntimeError, match="matrix-core kernel needs heads of 32 / 64 / 96 / 128"):
         hip.op_attention(segs(lens), segs(lens), dev(q), dev(k), dev(v), heads, kc, kernel=2)
