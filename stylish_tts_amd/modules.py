@@ -383,15 +383,19 @@ class STFT(torch.nn.Module):
         return self._engine
 
     def transform(self, waveform: torch.Tensor):
-        """waveform [B, T] (T a multiple of the hop) -> magnitude, x, y [B, 1025, T / hop + 1] (stft.py:98-139)."""
+        """waveform [B, T] -> magnitude, x, y [B, 1025, T // hop + 1] (stft.py:98-139), any T like the reference.
+        A tail shorter than a hop: the reference pads by REPLICATION, so extending the waveform to the next multiple of the hop with copies of its
+        last sample leaves every frame it produces unchanged and appends one frame, which is dropped."""
         eng, hop = self.engine, self.hop_length
         B, T = waveform.shape
-        if T % hop:
-            raise ValueError("STFT.transform: the HIP path needs T to be a multiple of hop_length")
         F = T // hop + 1
-        seg = Segments([F] * B, eng.device)
-        mag, x, y = eng.conv_stft_transform(seg, _f(waveform, eng.device).reshape(-1), hop)
-        return tuple(eng.to_channel_major(v, B, self.freq_bins, F) for v in (mag, x, y))
+        wave = _f(waveform, eng.device)
+        if T % hop:
+            wave = torch.cat([wave, wave[:, -1:].expand(B, hop - T % hop)], dim=1)
+        Fk = wave.shape[1] // hop + 1
+        seg = Segments([Fk] * B, eng.device)
+        mag, x, y = eng.conv_stft_transform(seg, wave.reshape(-1).contiguous(), hop)
+        return tuple(eng.to_channel_major(v, B, self.freq_bins, Fk)[:, :, :F].contiguous() for v in (mag, x, y))
 
     def inverse(self, magnitude: torch.Tensor, x: torch.Tensor, y: torch.Tensor, length=None):
         """[B, 1025, F] x 3 -> waveform [B, 1, (F - 1) * hop] (stft.py:141-187)."""

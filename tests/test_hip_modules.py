@@ -306,6 +306,23 @@ def test_conv_stft_module_shim(cfg):
     assert torch.equal(back[:900], b0.reshape(-1))
 
 
+def test_conv_stft_shim_takes_any_length(cfg):
+    """models/stft.py's transform accepts any T (T // hop + 1 frames, replicate padding); the shim extends a ragged tail by replication and
+    drops the extra frame.  Against the oracle's restatement, which pads like the reference, for hops 75 and 300."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import modules, synth
+
+    for hop, T in ((75, 1000), (300, 2500), (75, 74)):
+        st = modules.STFT(filter_length=2048, hop_length=hop, win_length=1200, cfg=cfg)
+        w = (synth.normal(f"stft.any{hop}.{T}", (2, T)) * 0.3).astype(np.float32)
+        mag, x, y = st.transform(dev(w))
+        rm, rx, ry = O.conv_stft_transform(w, hop=hop)
+        assert mag.shape == rm.shape == (2, 1025, T // hop + 1)
+        close(mag, rm, rtol=2e-5, what=f"conv STFT magnitude, hop {hop}, T {T}")
+        strong = rm > 1e-3
+        assert np.abs(x.cpu().numpy() - rx)[strong].max() < 2e-3 and np.abs(y.cpu().numpy() - ry)[strong].max() < 2e-3
+
+
 def test_synthesizer_vs_the_oracle_chain(mods, weights, cfg):
     """pipeline.Synthesizer (tokens -> waveforms, one packed pass) against the ORACLE's restatement of the reference chain
     DurationPredictor -> DurationProcessor -> ExportModel: durations bit-equal, predicted pitch / energy

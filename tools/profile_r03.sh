@@ -2,6 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): one bench JSON + one `rocprofv3 --kernel-trace --stats` summary per number README / DESIGN quote.
 #   cfg2        bench.py (the bench line: B = 8 x 3 s fp32; roofline, in-run --pmc traffic, cpu_baseline, legs)
 #   bf16_b64    --batch 64 --precision bf16 (cfg3-shaped frame path)       f16_16x10s  --batch 16 --mel-frames 800 --precision f16 (cfg5-shaped)
+#   cfg3        --workload cfg3 (tokens -> waveform, 64 x 50 tokens, bf16 frame path)
 #   b1          --batch 1 (latency)                                        cfm / full_chain: tools/cfm_bench.py, tools/full_chain_bench.py
 # tools/kstats.py turns <name>_kernel_stats.csv into the per-kernel tables under profiles/.
 set -o pipefail
@@ -26,8 +27,13 @@ for cfgline in "bf16_b64 --batch 64 --precision bf16" "f16_16x10s --batch 16 --m
   timeout -k 10 200 python3 bench.py "$@" --no-cpu-baseline --no-traffic --no-legs > "$O/${name}_bench.json" 2> "$O/${name}_bench.err"
   trace "$name" bench.py "$@" --no-cpu-baseline --no-traffic --no-legs
 done
+timeout -k 10 200 python3 bench.py --workload cfg3 --steps 10 --warmup 2 > "$O/cfg3_bench.json" 2> "$O/cfg3_bench.err"
+trace cfg3 bench.py --workload cfg3 --steps 10 --warmup 2
 timeout -k 10 200 python3 tools/cfm_bench.py > "$O/cfm_bench.txt" 2>&1
 trace cfm tools/cfm_bench.py
 timeout -k 10 200 python3 tools/full_chain_bench.py > "$O/full_chain_bench.txt" 2>&1
 trace full_chain tools/full_chain_bench.py
+STTS_BENCH_ONE_GPU=1 STTS_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > "$O/n2_gloo_rehearsal_one_gpu.json" 2> "$O/n2_gloo_rehearsal_one_gpu.err"
+if [ -x tools/probes/bin/gemm16_probe ]; then ABL=2 timeout -k 10 300 tools/probes/bin/gemm16_probe > "$O/gemm16_ablation.txt" 2>&1; fi
+timeout -k 10 300 python3 tools/debug/cap_bench.py > "$O/capacity_bench.txt" 2>&1
 ls -la "$O"
