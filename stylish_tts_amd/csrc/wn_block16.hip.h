@@ -105,12 +105,16 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
   auto layer = [&](const int l, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     const f32x4* w1 = reinterpret_cast<const f32x4*>(a.W1[l]) + (size_t)w * TAPS * (T1 * 64) + lane;
-    f32x4 bq0[TH], bq1[TH];
+    // the weight stream runs TWO half taps (~1 us of MFMAs) ahead of the multiplies in three register buffers: with one half tap ahead
+    // (0.48 us) every half tap waited for L2 (this wave is alone on its SIMD: nothing else hides the latency)
+    // (three half taps ahead in four buffers, and the phase-2 weights requested before the gate, measured: 166 and 143 us per launch against 143 - spills / no gain)
+    f32x4 bq[3][TH];
     auto load1 = [&](f32x4(&dst)[TH], int half) {  // half = 2 tap + (0 | 1)
 #pragma unroll
       for (int j = 0; j < TH; ++j) dst[j] = w1[(half * TH + j) * 64];
     };
-    load1(bq0, 0);
+    load1(bq[0], 0);
+    load1(bq[1], 1);
     // ---- h (rounded) -> conv tile; rows outside the utterance are zero
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -151,16 +155,37 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
             for (int rt = 0; rt < RT; ++rt) acc[h][c][rt] = mfma16x16<PREC>(cur[(tt * 2 + h) * CT + c], av[rt], acc[h][c][rt]);
       }
     };
+    static_assert(2 * TAPS == 10, "the rolled loop below covers nine half taps in threes + one");
 #pragma unroll 1
-    for (int half = 0; half < 2 * TAPS; half += 2) {
-      load1(bq1, half + 1);
+    for (int h3 = 0; h3 < 9; h3 += 3) {  // (rolled: fully unrolled, the ten half taps' loads and fragments spill)
+      load1(bq[2], h3 + 2);
       __builtin_amdgcn_sched_barrier(0);
-      half_tap(half, bq0);
-      if (half + 2 < 2 * TAPS) load1(bq0, half + 2);
+      half_tap(h3, bq[0]);
+      load1(bq[0], h3 + 3);
       __builtin_amdgcn_sched_barrier(0);
-      half_tap(half + 1, bq1);
+      half_tap(h3 + 1, bq[1]);
+      if (h3 + 4 < 2 * TAPS) load1(bq[1], h3 + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      half_tap(h3 + 2, bq[2]);
     }
+    half_tap(9, bq[0]);
 
+    // ---- phase-2 weights of this layer (res | skip in block order; layer 3: skip only) + their bias
+    constexpr int NCT = LAST ? CT : 2 * CT;
+    const f32x4* w2 = reinterpret_cast<const f32x4*>(a.W2[l]) + (size_t)w * KS * (NCT * 64) + lane;
+    f32x4 cq2[KS][NCT];
+    f32x4 bh[CT], bo[CT];
+    auto load2 = [&]() {
+#pragma unroll
+      for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) cq2[t][c] = w2[(t * NCT + c) * 64];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        bh[c] = LAST ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.b2[l] + ch0 + 16 * c);
+        bo[c] = *reinterpret_cast<const f32x4*>(a.b2[l] + (LAST ? 0 : C) + ch0 + 16 * c);
+      }
+    };
     // ---- gate -> 16-bit activations in LDS
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -175,21 +200,8 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
         }
         put4(As, 16 * rt + l15, ch0 + 16 * c, act);
       }
-    __builtin_amdgcn_sched_barrier(0);  // (the phase-2 operands below are fetched once the conv accumulators are dead, not before)
-    // ---- phase-2 weights of this layer (res | skip in block order; layer 3: skip only) + their bias
-    constexpr int NCT = LAST ? CT : 2 * CT;
-    const f32x4* w2 = reinterpret_cast<const f32x4*>(a.W2[l]) + (size_t)w * KS * (NCT * 64) + lane;
-    f32x4 cq2[KS][NCT];
-#pragma unroll
-    for (int t = 0; t < KS; ++t)
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) cq2[t][c] = w2[(t * NCT + c) * 64];
-    f32x4 bh[CT], bo[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      bh[c] = LAST ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.b2[l] + ch0 + 16 * c);
-      bo[c] = *reinterpret_cast<const f32x4*>(a.b2[l] + (LAST ? 0 : C) + ch0 + 16 * c);
-    }
+    __builtin_amdgcn_sched_barrier(0);  // (the phase-2 operands are fetched once the conv accumulators are dead, not before)
+    load2();
     __syncthreads();
 
     // ---- phase 2: res / skip, K = 128 from LDS.  Skip: onto the register accumulator.  Res: the tile of h passes through the registers
