@@ -99,6 +99,10 @@ struct GemmArgs {
   int act;
   float* sumsq_part;  // optional: [utt * ss_stride + (32-row sub-tile index within the utterance)][ld_ss]
   int ld_ss, ss_stride;
+  // optional (conv_gemm16_kernel only): AdaIN statistics of the OUTPUT, per utterance and 128-row chunk, in adain_partial_kernel's layout
+  // stat_part[((utt * stat_nchunk + chunk) * 2 + {0: mean, 1: sum of squared deviations}) * ld_stat + channel] - the consumer's statistics pass disappears
+  float* stat_part;
+  int ld_stat, stat_nchunk;
   // EPI_GATE
   const float* gate;  // [n_utt][ld_gate]; a-part at gcol0 + c, b-part at gcol0 + gC + c
   int ld_gate, gcol0, gC;
@@ -1012,6 +1016,7 @@ inline double gemm_algorithmic_flops(const GemmArgs& a) {
 // conv_gemm16_kernel (gemm16.hip.h): the 16-bit-row store contractions of large batches
 inline bool gemm16_eligible(const GemmArgs& a, int epi, int npad);
 inline long gemm16_tiles(const GemmArgs& a, int npad, int n_utt);
+inline bool gemm16_will_run(const GemmArgs& a, int epi, int npad, int n_utt);  // would launch_conv_gemm pick conv_gemm16_kernel for this call?
 template <int ABL>
 inline int launch_conv_gemm16(hipStream_t st, const GemmArgs& a, int npad, int n_utt);
 
@@ -1073,10 +1078,10 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       STTS_CHECK(a.prec != PREC_F32 && a.seg[i].ldx % 8 == 0 && a.seg[i].xcol0 % 8 == 0, "conv_gemm: 16-bit activation rows need ldx / xcol0 multiples of 8 (segment %d)", i);
   // 16-bit activation rows, store epilogue, at least ~one 256 x 256 tile per CU: the persistent LDS-DMA kernel (gemm16.hip.h).
   // force_tile 19 selects it whatever the size (tests), any other forced tile keeps the launch on conv_gemm_f32.
-  if ((force_tile == 0 || force_tile == 19) && gemm16_eligible(a, epi, npad)) {
-    static const long min_tiles = getenv("STTS_GEMM16_MIN_TILES") ? atol(getenv("STTS_GEMM16_MIN_TILES")) : 192;
-    if (force_tile == 19 || gemm16_tiles(a, npad, n_utt) >= min_tiles) return launch_conv_gemm16<0>(st, a, npad, n_utt);
+  if (force_tile == 19 || (force_tile == 0 && gemm16_will_run(a, epi, npad, n_utt))) {
+    if (gemm16_eligible(a, epi, npad)) return launch_conv_gemm16<0>(st, a, npad, n_utt);
   }
+  STTS_CHECK(!a.stat_part, "conv_gemm: output statistics (stat_part) exist only in conv_gemm16_kernel's epilogue: ask gemm16_will_run first");
   STTS_CHECK(force_tile != 19, "conv_gemm: tile 19 (conv_gemm16_kernel) needs 16-bit activation rows, a store epilogue, channels in multiples of 64 and cout padded to 256");
   constexpr int kCUs = 256;
   const int mt = npad / 128;

@@ -306,9 +306,10 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
     float* const Yb = hasY ? a.Y + (long)row0 * a.ldy + a.ycol0 + m0 + cl : nullptr;
     const float* const Rb = hasR ? a.R + (long)row0 * a.ldr + a.rcol0 + m0 + cl : nullptr;
     unsigned short* const Y16b = hasY16 ? a.Y16 + (long)row0 * a.ldy16 + a.ycol16 + m0 + cl : nullptr;
-    f32x4 ss[4];
+    const bool hasST = a.stat_part != nullptr;
+    f32x4 ss[4], su[4];
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) ss[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tn = 0; tn < 4; ++tn) ss[tn] = su[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tm = 0; tm < 8; ++tm) {
       const int tr = tl + tm * 16;
@@ -330,6 +331,34 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
             else *reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)) = pack4_16<PREC>(vv);
           }
           ss[tn] += vv * vv;
+          su[tn] += vv;
+        }
+      }
+    }
+    if (hasST) {
+      // AdaIN statistics of this wave's 128 rows = chunk 2 local + wr of the utterance (adain_partial_kernel's chunks are 128 rows from the
+      // utterance's first): mean and sum of squared deviations per channel from the sums over the valid rows (fp32: n <= 128 values of O(1))
+      const int chunk = local * 2 + wr, nc = min(128, len - chunk * 128);
+      if (nc > 0) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          f32x4 s1 = su[tn], s2 = ss[tn];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s1[e] += __shfl_xor(s1[e], o, 64);
+              s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+          if (frow == 0 && nok[tn]) {
+            const f32x4 mean = s1 * (1.0f / (float)nc);
+            f32x4 m2 = s2 - mean * s1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m2[e] = fmaxf(m2[e], 0.0f);
+            float* p = a.stat_part + ((long)(utt * a.stat_nchunk + chunk) * 2) * a.ld_stat + m0 + cl + tn * 16;
+            *reinterpret_cast<f32x4*>(p) = mean;
+            *reinterpret_cast<f32x4*>(p + a.ld_stat) = m2;
+          }
         }
       }
     }
@@ -360,10 +389,15 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
 // cout padded to 256, N a multiple of 4, host offsets known (compact grid).
 inline bool gemm16_eligible(const GemmArgs& a, int epi, int npad) {
   if (epi != EPI_STORE || a.prec == PREC_F32 || !a.x16 || !a.seg_host || a.xaff || npad % kG16Tile != 0 || a.N % 4 != 0) return false;
-  if (a.ldy % 4 || a.ycol0 % 4 || a.ldr % 4 || a.rcol0 % 4 || a.ldy16 % 4 || a.ycol16 % 4 || a.ld_ss % 4) return false;
+  if (a.ldy % 4 || a.ycol0 % 4 || a.ldr % 4 || a.rcol0 % 4 || a.ldy16 % 4 || a.ycol16 % 4 || a.ld_ss % 4 || a.ld_stat % 4) return false;
   for (int i = 0; i < a.nseg; ++i)
     if (a.seg[i].kc % kG16K != 0 || a.seg[i].ldx % 8 != 0 || a.seg[i].xcol0 % 8 != 0 || !a.seg[i].W16 || a.seg[i].ldx - a.seg[i].xcol0 < a.seg[i].kc) return false;
   return true;
+}
+
+inline bool gemm16_will_run(const GemmArgs& a, int epi, int npad, int n_utt) {
+  static const long min_tiles = getenv("STTS_GEMM16_MIN_TILES") ? atol(getenv("STTS_GEMM16_MIN_TILES")) : 192;
+  return gemm16_eligible(a, epi, npad) && gemm16_tiles(a, npad, n_utt) >= min_tiles;
 }
 
 // 256 x 256 tiles of the launch: exact from the host offsets (an upper bound when they are capacities)

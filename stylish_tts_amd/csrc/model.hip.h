@@ -883,9 +883,11 @@ inline long rows16_threshold() {
 inline size_t adain_part_floats(const Seg& s, int C) { return (size_t)s.n_utt * ceil_div(s.max_len(), kStatChunk) * 2 * round_up(C, 32); }
 // out16: PREC_BF16 / PREC_F16 = Y is a 16-bit row buffer (ldy in elements), the input of a contraction in that operand mode
 inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int C, float* Y, int ldy, const float* style_out, int ld_style,
-                     int gcol0, int act, const float* alpha, float* part, int out16 = 0) {
+                     int gcol0, int act, const float* alpha, float* part, int out16 = 0, bool have_stats = false) {
+  // have_stats: `part` already holds the chunk statistics of X (written by the producing contraction's epilogue, GemmArgs::stat_part)
   const int nchunk = ceil_div(s.max_len(), kStatChunk), ldp = round_up(C, 32);
-  STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk);
+  if (!have_stats)
+    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk);
   const int rb = (long)ceil_div(ldy, 64) * ceil_div(s.rows(), 64) >= 4096 ? 256 : 64;  // rows per block
   STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C * 4 + ldy * (out16 ? 2 : 4)), adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), rb), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
                      part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha, out16, rb);
@@ -893,12 +895,25 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
   return 0;
 }
 
+struct AdainStats {
+  float* in = nullptr;   // statistics of x for norm1 (layout of adain_partial_kernel, round_up(cin, 32) columns)
+  bool in_ready = false;
+  float* mid = nullptr;  // scratch: statistics of conv1's output for norm2
+  float* out = nullptr;  // where conv2 writes the statistics of y
+  int out_ld = 0;
+  bool out_ready = false;
+};
 // AdaptiveDecoderBlock (models/ada_norm.py:166-182).  x [rows, ldx] (cols >= cin may hold anything when
 // kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
 // scratch: act1 [rows, kcin], h [rows, cout], act2 [rows, cout], ss [adain_part_floats(s, max(kcin, cout))]
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
                            float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr,
-                           unsigned short* xs16 = nullptr, bool xs16_ready = false, unsigned short* y16 = nullptr, int ldy16 = 0) {
+                           unsigned short* xs16 = nullptr, bool xs16_ready = false, unsigned short* y16 = nullptr, int ldy16 = 0,
+                           AdainStats* stats = nullptr) {
+  // stats (16-bit modes, large batches; decoder_forward): statistics written by the producing contractions' epilogues (conv_gemm16_kernel,
+  // GemmArgs::stat_part) instead of a pass of adain_partial_kernel per norm - norm1's come from the previous block's conv2 (`in`, if `in_ready`),
+  // norm2's from this block's conv1 (`mid`), and conv2 leaves those of y for the next block's norm1 in `out` (`out_ld` columns per row, the
+  // next block's padded input width; its constant columns are filled once by the caller); `out_ready` reports whether it did.
   // xs16: [rows, ldx] 16-bit scratch for the rounded copy of x a learned shortcut reads (16-bit modes, large batches);
   // xs16_ready: it already holds that copy (the previous block's conv2 wrote it).  y16: also write y rounded, as [rows, ldy16].
   const int ml = s.max_len();
@@ -928,11 +943,15 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   // 16-bit operand modes, large batches: the normalised activations are WRITTEN as 16-bit rows (act1 / act2 reinterpreted),
   // so the contractions stage half the bytes and convert nothing; a learned shortcut reads a rounded copy of x (xs16)
   const int h16 = (s.rows() >= rows16_threshold() && B.conv1.prec != PREC_F32 && force_tile == 0 && (!B.sc.W || xs16) && ldx % 8 == 0) ? B.conv1.prec : 0;
+  const int nchunk = ceil_div(ml, kStatChunk);
+  const bool fuse_stats = stats && h16 && !fold && !wino1 && !wino2;
   if (!fold && !wino1) {
-    STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ss, h16));
+    const bool ready = fuse_stats && stats->in_ready;
+    STTS_TRY(run_adain(st, s, x, ldx, B.cin, act1, B.kcin, style_out, ld_style, B.n1.col0, ACT_LRELU, nullptr, ready ? stats->in : ss, h16, ready));
     set_seg(a, 0, act1, B.kcin, 0, B.conv1);
     a.x16 = h16 != 0;
   }
+  if (stats) stats->out_ready = false;
   a.N = B.cout;
   a.bias = B.conv1.bias;
   a.Y = hbuf;
@@ -943,8 +962,12 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1);
     STTS_TRY(run_winograd(st, s, x, ldx, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino, act1, B.kcin));
   } else {
+    if (fuse_stats && gemm16_will_run(a, EPI_STORE, B.conv1.npad, s.n_utt)) {
+      a.stat_part = stats->mid; a.ld_stat = round_up(B.cout, 32); a.stat_nchunk = nchunk;
+    }
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
   }
+  const bool mid_ready = a.stat_part != nullptr;
   // norm2 -> LeakyReLU -> conv2 (+ learned 1x1 shortcut as a second K segment | + identity residual), / sqrt(2)
   GemmArgs b = gemm_args(s);
   if (fold) {
@@ -955,7 +978,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   } else if (wino2) {
     affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2);
   } else {
-    STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, ss, h16));
+    STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, mid_ready ? stats->mid : ss, h16, mid_ready));
     set_seg(b, 0, act2, B.cout, 0, B.conv2);
     b.x16 = h16 != 0;
   }
@@ -983,6 +1006,10 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   if (wino2) {
     STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, *wino, act2, B.cout));
   } else {
+    if (fuse_stats && stats->out && gemm16_will_run(b, EPI_STORE, B.conv2.npad, s.n_utt)) {
+      b.stat_part = stats->out; b.ld_stat = stats->out_ld; b.stat_nchunk = nchunk;
+      stats->out_ready = true;
+    }
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
   }
   if (y16 && !y16_epi) launch_cast_rows(st, B.conv1.prec, y, ldy, B.cout, y16, ldy16, s.rows(), B.cout);  // (cout % 8 == 0: caller)
@@ -1010,6 +1037,8 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* hbuf = ws.get<float>(R * d.dec_hidden);
   float* act2 = ws.get<float>(R * d.dec_hidden);
   float* ss = ws.get<float>(adain_part_floats(s, ldwide));
+  float* ss_in = ws.get<float>(adain_part_floats(s, ldwide));   // 16-bit modes: statistics from the contractions' epilogues (AdainStats)
+  float* ss_mid = ws.get<float>(adain_part_floats(s, ldwide));
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
@@ -1042,10 +1071,23 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     launch_cast_rows(st, c->prec, src + ctail, ldcat, ccat - ctail, dst + ctail, ldcat, R, ntail);
   };
   // dec[0] rounds its own (narrow) input into xs16b as scratch, so xs16b's constant columns are filled after it
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat));
+  // 16-bit modes, large batches: the statistics of a block's input come out of the previous block's conv2 epilogue (its 512 hidden columns) and,
+  // for the constant columns [asr_res | F0 | N] that every decode block sees, from ONE statistics pass here
+  static const bool no_stat_fuse = getenv("STTS_NO_STAT_FUSE") != nullptr;  // experiments: every norm runs its own statistics pass
+  AdainStats stats;
+  stats.mid = ss_mid;
+  stats.out = ss_in;
+  stats.out_ld = round_up(ccat, 32);
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat, (x16 && !no_stat_fuse) ? &stats : nullptr));
   if (x16) {
     cast_tail(xa, xs16a);
     cast_tail(xb, xs16b);
+  }
+  if (stats.out_ready) {
+    const int nchunk = ceil_div(s.max_len(), kStatChunk), cc0 = d.dec_hidden, ncst = ccat - cc0;
+    STTS_CHECK(cc0 % 32 == 0, "decoder_forward: hidden_dim must be a multiple of 32");
+    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)R * ncst * 4, adain_partial_kernel, dim3(ceil_div(ncst, 32), nchunk, s.n_utt), dim3(256), st, xa + cc0, ldcat, ncst, s.dev,
+                     ss_in + cc0, stats.out_ld, nchunk);
   }
   float* cur = xa;
   float* nxt = xb;
@@ -1054,7 +1096,11 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   for (int i = 1; i <= 4; ++i) {
     float* dst = i == 4 ? x_out : nxt;
     const int ldd = i == 4 ? ld_x : ldcat;
-    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat));
+    stats.in = ss_in;
+    stats.in_ready = stats.out_ready;  // (the previous block's conv2 ran on conv_gemm16_kernel and left the statistics of its output)
+    stats.out = i == 4 ? nullptr : ss_in;
+    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat,
+                             (x16 && !no_stat_fuse) ? &stats : nullptr));
     std::swap(cur, nxt);
     std::swap(cur16, nxt16);
   }
