@@ -1577,7 +1577,7 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     else { a.Y = U; a.ldy = inter; }
     a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
-    STTS_LAUNCH_PROF("grn_gx_kernel", (size_t)s.n_utt * ss_stride * inter * 4, grn_gx_kernel, dim3(ceil_div(inter, 256), s.n_utt), dim3(256), st, part, inter, ss_stride, s.dev, inter, gscale, inter);
+    STTS_LAUNCH_PROF("grn_gx_kernel", (size_t)s.n_utt * ss_stride * inter * 4, grn_gx_kernel, dim3(ceil_div(inter, 32), s.n_utt), dim3(256), st, part, inter, ss_stride, s.dev, inter, gscale, inter);
     launch_scale_weight(st, dim3(128, s.n_utt), B.pw2.prec, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, U, inter, 0, B.pw2);

@@ -376,7 +376,7 @@ inline int text_style_forward(stts_ctx* c, hipStream_t st, const StyleEncW& W, c
     a.N = inter4; a.bias = B.pw1.bias; a.Y = U; a.ldy = inter4; a.act = ACT_GELU;
     a.sumsq_part = part; a.ld_ss = inter4; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
-    hipLaunchKernelGGL(grn_gx_kernel, dim3(ceil_div(inter4, 256), s.n_utt), dim3(256), 0, st, part, inter4, ss_stride, s.dev, inter4, gx, inter4);
+    hipLaunchKernelGGL(grn_gx_kernel, dim3(ceil_div(inter4, 32), s.n_utt), dim3(256), 0, st, part, inter4, ss_stride, s.dev, inter4, gx, inter4);
     launch_scale_weight(st, dim3(8, s.n_utt), B.pw2.prec, B.pw2.W, gx, inter4, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, U, inter4, 0, B.pw2);
