@@ -97,26 +97,55 @@ __global__ void __launch_bounds__(64) small_layernorm_kernel(const float* __rest
 
 // Source features of one utterance (cfm_mel_decoder.py:321-330): F0 / N resampled to n frames by F.interpolate's 'nearest' rule,
 // SineGenerator with one component (:54-104; the random initial phase of the fundamental is zeroed, :68; torch's CPU cumsum of
-// fp32 accumulates in double and rounds every partial sum to fp32, reproduced here), merge = tanh(w * s), then
-// har[row] = (source, N, t, 0 ...) in a 32-column buffer.  One block per utterance; the two running sums are sequential.
-__global__ void __launch_bounds__(64) cfm_source_kernel(const float* __restrict__ f0, const float* __restrict__ ncurve, const int* __restrict__ curve_off,
-                                                        const int* __restrict__ seg_off, const float* __restrict__ t, const float* __restrict__ noise,
-                                                        float merge_w, float* __restrict__ har, int ldh) {
-  const int u = blockIdx.x;
+// fp32 accumulates in double and rounds every partial sum to fp32 where it is used, reproduced here), merge = tanh(w * s), then
+// har[row] = (source, N, t, 0 ...) in a 32-column buffer.  One block of 256 threads per utterance.  The two running sums are PREFIX
+// SUMS IN DOUBLE of fp32 terms (rad in [0, 1), rad + shift in (-1, 1), at most a few thousand of them): every partial sum is exact in
+// 53 bits, so a blocked scan gives bit for bit what the sequential loop gives (round 2 walked the frames with one thread: 0.43 ms at
+// 8 x 800 frames, 6 % of an estimator evaluation).
+__global__ void __launch_bounds__(256) cfm_source_kernel(const float* __restrict__ f0, const float* __restrict__ ncurve, const int* __restrict__ curve_off,
+                                                         const int* __restrict__ seg_off, const float* __restrict__ t, const float* __restrict__ noise,
+                                                         float merge_w, float* __restrict__ har, int ldh) {
+  __shared__ double part[256];
+  const int u = blockIdx.x, tid = threadIdx.x;
   const int lo = seg_off[u], n = seg_off[u + 1] - lo;
   const int clo = curve_off[u], L = curve_off[u + 1] - clo;
   const float scale = (float)L / (float)n;
   auto src_idx = [&](int i) { return L == n ? i : min((int)floorf((float)i * scale), L - 1); };
-  for (int i = threadIdx.x; i < n; i += 64) {
+  for (int i = tid; i < n; i += 256) {
     float* h = har + (long)(lo + i) * ldh;
     h[1] = ncurve[clo + src_idx(i)];
     h[2] = t[u];
     for (int c = 3; c < ldh; ++c) h[c] = 0.f;
   }
-  if (threadIdx.x != 0) return;
-  double c1 = 0.0, c2 = 0.0;  // cumsum(rad), cumsum(rad + shift)
-  float prev = 0.f;
-  for (int i = 0; i < n; ++i) {
+  // thread tid owns frames [a, b): exclusive prefix over the threads through LDS, then the running sum inside the chunk
+  const int per = (n + 255) / 256, a = min(n, tid * per), b = min(n, a + per);
+  auto rad_of = [&](int i) { return fmodf(f0[clo + src_idx(i)] / 24000.0f, 1.0f); };
+  auto block_exclusive = [&](double mine) {  // sum of `mine` over the threads before this one (fixed order; exact, see above)
+    __syncthreads();
+    part[tid] = mine;
+    __syncthreads();
+    double run = 0.0;
+    for (int k = 0; k < tid; ++k) run += part[k];
+    return run;
+  };
+  double s1 = 0.0;
+  for (int i = a; i < b; ++i) s1 += (double)rad_of(i);
+  double c1 = block_exclusive(s1);  // cumsum(rad) before frame a
+  // shift[i] needs fmod(cumsum(rad)[i]) and the same of frame i - 1
+  float prev = a > 0 ? fmodf((float)c1, 1.0f) : 0.f;
+  double s2 = 0.0;
+  for (int i = a; i < b; ++i) {
+    const float rad = rad_of(i);
+    c1 += (double)rad;
+    const float tmp = fmodf((float)c1, 1.0f);
+    const float shift = (i > 0 && tmp - prev < 0.f) ? -1.0f : 0.0f;
+    prev = tmp;
+    s2 += (double)(rad + shift);
+  }
+  double c2 = block_exclusive(s2);  // cumsum(rad + shift) before frame a
+  c1 -= s1;                         // back to the prefix before frame a
+  prev = a > 0 ? fmodf((float)c1, 1.0f) : 0.f;
+  for (int i = a; i < b; ++i) {
     const float f = f0[clo + src_idx(i)];
     const float rad = fmodf(f / 24000.0f, 1.0f);
     c1 += (double)rad;
@@ -373,7 +402,8 @@ inline int cfm_estimator(stts_ctx* c, const CfmModel& M, hipStream_t st, const S
   STTS_CHECK(ws.ok, "cfm_estimator: workspace too small");
   STTS_DRY_RETURN(ws);
   STTS_CHECK(ld_x >= d.feat && ld_asr % 32 == 0 && ld_asr >= d.asr && ld_out >= d.feat, "cfm_estimator: leading dimensions too small (asr rows must be padded to 32 columns)");
-  STTS_CHECK(s.max_len() <= kAttnMaxKeys, "cfm_estimator: utterances of more than %d frames are not supported (%d)", kAttnMaxKeys, s.max_len());
+  STTS_CHECK(attn_mfma_kc(d.head_dim) || s.max_len() <= kAttnMaxKeys, "cfm_estimator: with head_dim %d utterances of more than %d frames are not supported (%d)", d.head_dim,
+             kAttnMaxKeys, s.max_len());
   // conditioning that does not depend on x
   STTS_TRY(cfm_linear(st, s, asr, ld_asr, M.asr1, ACT_NONE, a1, 4 * d.emb));
   hipLaunchKernelGGL(mish_kernel, dim3((unsigned)std::min<long>(2048, ceil_div(R * d.emb, 256L))), dim3(256), 0, st, a1, R * d.emb);  // R * 4 emb / 4 float4s
@@ -381,7 +411,7 @@ inline int cfm_estimator(stts_ctx* c, const CfmModel& M, hipStream_t st, const S
   STTS_TRY(run_small(st, M.spk0, spk, d.spk, 1, s1, 4 * d.emb, U));
   STTS_TRY(run_small(st, M.spk2, s1, 4 * d.emb, 0, se, d.emb, U));
   hipLaunchKernelGGL(broadcast_style_kernel, dim3(std::max(1, ceil_div(s.max_len() * d.emb, 256)), U), dim3(256), 0, st, se, d.emb, d.emb, sb, d.emb, 0, s.dev);
-  hipLaunchKernelGGL(cfm_source_kernel, dim3(U), dim3(64), 0, st, f0, ncurve, curve_off_dev, s.dev, t, noise, M.merge_w, har, 32);
+  hipLaunchKernelGGL(cfm_source_kernel, dim3(U), dim3(256), 0, st, f0, ncurve, curve_off_dev, s.dev, t, noise, M.merge_w, har, 32);
   // x + prior_generator(har) (k = 7 conv over the three source features), then in_proj over [x | asr_emb | spk_emb] as three K segments
   // (xp's pad columns meet zero weights in in_proj, but the contraction reads them: they must be finite)
   if (ldf > d.feat) STTS_HIP(hipMemsetAsync(xp, 0, (size_t)R * ldf * sizeof(float), st));

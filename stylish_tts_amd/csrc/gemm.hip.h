@@ -1183,7 +1183,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   if (splittable && tile != 8 && plan.rem_rt == 0) {
     const long blocks = plan.full_rt * mt;
     // (16-bit operands: a contraction that already has one tile per CU is shorter than the reduce pass it would add)
-    main_ksp = (int)std::min<long>(8, std::min<long>(iters / 4, (a.prec == PREC_F32 ? 512 : 255) / std::max<long>(blocks, 1)));
+    static const int min_it = getenv("STTS_SPLITK_MIN_ITERS") ? std::max(1, atoi(getenv("STTS_SPLITK_MIN_ITERS"))) : 4;  // K iterations left per slice (experiments)
+    main_ksp = (int)std::min<long>(8, std::min<long>(iters / min_it, (a.prec == PREC_F32 ? 512 : 255) / std::max<long>(blocks, 1)));
     if (main_ksp < 2) main_ksp = 1;
   }
   float* part = nullptr;

@@ -166,3 +166,38 @@ def test_hip_graph_sampling_equals_eager_sampling():
     graph = m(*args, z=d(g["sample_z"]), sine_noise=nzs, graph=True)
     assert torch.equal(eager, graph)
     assert np.abs(graph.cpu().numpy() - g["sample_y"]).max() < 1e-4 * np.abs(g["sample_y"]).max()
+
+
+@pytest.mark.gpu
+def test_hip_estimator_beyond_1024_frames():
+    """An utterance of 1 100 frames (the matrix-core attention streams the keys: no 1 024-key limit with head_dim 64) next to a short one,
+    against the oracle; also exercises the blocked double-precision prefix sums of the sine source over more than four frames per thread."""
+    import torch
+
+    from stylish_tts_amd import synth
+    from stylish_tts_amd.runtime import Segments
+
+    dims = CASES["small"]
+    m, sd = _hip(dims), _weights(dims)
+    lens = [1100, 37]
+    rng = lambda nm, shape: synth.normal("cfml." + nm, shape)  # noqa: E731
+    xs = [rng(f"x{i}", (1, dims["feat_dim"], n)) for i, n in enumerate(lens)]
+    asrs = [rng(f"a{i}", (1, dims["asr_dim"], n)) for i, n in enumerate(lens)]
+    f0s = [synth.pitch_curve(f"cfml.f{i}", 1, n) for i, n in enumerate(lens)]
+    ncs = [(synth.uniform(f"cfml.n{i}", (1, n)) * 2 + 2).astype(np.float32) for i, n in enumerate(lens)]
+    spk = rng("spk", (2, dims["spk_dim"]))
+    t = np.array([0.3, 0.8], np.float32)
+    nzs = [rng(f"z{i}", (1, n, 1)) for i, n in enumerate(lens)]
+    dev = m.device
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ld_asr = (dims["asr_dim"] + 31) // 32 * 32
+    ar = torch.zeros(sum(lens), ld_asr, device=dev)
+    ar[:, : dims["asr_dim"]] = d(np.concatenate([a[0].T for a in asrs]))
+    seg = Segments(lens, dev)
+    out = m.estimator_packed(seg, d(np.concatenate([x[0].T for x in xs])), ar, d(np.concatenate([f[0] for f in f0s])), d(np.concatenate([c[0] for c in ncs])), seg,
+                             d(spk), d(t), d(np.concatenate([z.reshape(-1) for z in nzs]))).cpu().numpy()
+    for i, n in enumerate(lens):
+        ref = O.cfm_mel_decoder_forward(xs[i], asrs[i], f0s[i], ncs[i], spk[i : i + 1], t[i : i + 1], nzs[i], sd, dims)[0].T
+        got = out[seg.host[i] : seg.host[i + 1]]
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())

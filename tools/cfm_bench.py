@@ -12,7 +12,10 @@ g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "cf
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 y = m._forward(d(g["default_x"]), d(g["default_asr"]), d(g["default_f0"]), d(g["default_n"]), d(g["default_spk"]), d(g["default_t"]), sine_noise=d(g["default_nz"])).cpu().numpy()
 print("estimator vs reference (class defaults, B=2 x 53 frames): max-abs err %.2e of max %.2f" % (np.abs(y - g["default_y"]).max(), np.abs(g["default_y"]).max()))
-for B, n in ((1, 240), (8, 240), (32, 240), (8, 800)):
+shapes = ((1, 240), (8, 240), (32, 240), (8, 800))
+if os.environ.get("CFM_ONLY"):  # e.g. CFM_ONLY=8x800: one shape (for a rocprofv3 trace of it)
+    shapes = (tuple(int(v) for v in os.environ["CFM_ONLY"].split("x")),)
+for B, n in shapes:
     x = d(synth.normal("cb.x", (B, 80, n))); asr = d(synth.normal("cb.a", (B, 768, n))); f0 = d(synth.pitch_curve("cb.f", B, n))
     nc = d((synth.uniform("cb.n", (B, n)) * 2 + 2).astype(np.float32)); spk = d(synth.normal("cb.s", (B, 1024))); t = d(np.full((B,), 0.4, np.float32))
     nz = d(synth.normal("cb.z", (B, n, 1)))
