@@ -138,6 +138,90 @@ __global__ void __launch_bounds__(256) adain_partial_kernel(const float* __restr
   }
 }
 
+// A split-K contraction's reduce pass, handed to the consumer (GemmArgs::defer): Y[row][c] = (act(sum_k partial[k][row][c] + bias[c]) [+ R]) * alpha
+// for c < N - splitk_reduce_kernel's arithmetic and order.
+struct SplitSrc {
+  const float* partial;  // null: nothing pending, the rows are read from X
+  int ksplit, slice_rows, ld_part, N;
+  const float* bias;
+  int act;
+  const float* R;
+  int ldr, rcol0;
+  float alpha;
+};
+// adain_partial_kernel whose input rows are (for channels < src.N) still the partial sums of a split-K contraction: the block finishes them, WRITES
+// them to X and takes the statistics from the values in flight - the reduce pass and the statistics pass of a small-batch AdaIN in one launch.
+__global__ void __launch_bounds__(256) adain_partial_reduce_kernel(float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
+                                                                   float* __restrict__ part, int ldp, int nchunk, const SplitSrc src) {
+  __shared__ float red[8][33];
+  const int u = blockIdx.z, ch = blockIdx.y;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), cl = threadIdx.x & 31;
+  const int rl = threadIdx.x >> 5;
+  const int lo = seg_off[u] + ch * kStatChunk, hi = min(seg_off[u + 1], lo + kStatChunk);
+  if (lo >= hi) return;
+  const bool ok = c < C, pend = ok && c < src.N;
+  const float bv = (pend && src.bias) ? src.bias[c] : 0.f;
+  float v[kStatChunk / 8];
+#pragma unroll
+  for (int i = 0; i < kStatChunk / 8; ++i) v[i] = 0.f;
+  if (pend) {
+    // slice by slice, the 16 rows of a slice as one batch of independent loads (a per-row loop over the slices is 16 x ksplit dependent round trips)
+    for (int k = 0; k < src.ksplit; ++k) {
+      const float* pk = src.partial + ((long)k * src.slice_rows) * src.ld_part + c;
+#pragma unroll
+      for (int i = 0; i < kStatChunk / 8; ++i) {
+        const int r = lo + rl + 8 * i;
+        v[i] += pk[(long)min(r, hi - 1) * src.ld_part];  // (0 + p0 = p0: the sums are splitk_reduce_kernel's, slice 0 first)
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kStatChunk / 8; ++i) {
+      const int r = lo + rl + 8 * i;
+      float x = act_apply(v[i] + bv, src.act);
+      if (src.R) x += src.R[(long)min(r, hi - 1) * src.ldr + src.rcol0 + c];
+      x *= src.alpha;
+      if (r < hi) X[(long)r * ldx + c] = x;
+      v[i] = r < hi ? x : 0.f;
+    }
+  } else if (ok) {
+#pragma unroll
+    for (int i = 0; i < kStatChunk / 8; ++i) {
+      const int r = lo + rl + 8 * i;
+      const float x = X[(long)min(r, hi - 1) * ldx + c];
+      v[i] = r < hi ? x : 0.f;
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < kStatChunk / 8; ++i) acc += v[i];
+  red[rl][cl] = acc;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mean += red[i][cl];
+  mean /= (float)(hi - lo);
+  __syncthreads();
+  acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < kStatChunk / 8; ++i) {
+    const int r = lo + rl + 8 * i;
+    if (r < hi) {
+      const float d = v[i] - mean;
+      acc += d * d;
+    }
+  }
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && ok) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m2 += red[i][cl];
+    float* p = part + ((long)(u * nchunk + ch) * 2) * ldp;
+    p[c] = mean;
+    p[ldp + c] = m2;
+  }
+}
+
 // merge of the chunk statistics of channel c of utterance u (len rows) with the style affine:
 //   (1 + gamma) * (x - mean) * rstd + beta = x * scale + shift
 __device__ __forceinline__ void adain_scale_shift(const float* __restrict__ part, int ldp, int nchunk, int u, int c, int len,

@@ -895,6 +895,31 @@ inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int 
   return 0;
 }
 
+// A contraction whose split-K reduce pass is left to the consumer of its output (small batches: the next AdaIN's statistics kernel finishes it).
+struct PendingReduce {
+  SplitSrc src{};   // src.partial == nullptr: nothing pending
+  float* Y = nullptr;
+  int ldy = 0;
+};
+inline void pending_from(PendingReduce* p, const SplitInfo& info, const GemmArgs& a) {
+  p->src = SplitSrc{};
+  if (info.ksplit > 1) {
+    p->src = SplitSrc{info.partial, info.ksplit, info.slice_rows, info.ld_part, a.N, a.bias, a.act, a.R, a.ldr, a.rcol0, a.alpha};
+    p->Y = a.Y + a.ycol0;
+    p->ldy = a.ldy;
+  }
+}
+// finishes a pending reduce on its own (no consumer took it)
+inline int pending_finish(hipStream_t st, PendingReduce* p) {
+  if (!p || !p->src.partial) return 0;
+  const SplitSrc& r = p->src;
+  const long work = (long)r.slice_rows * ((r.N + 3) / 4);
+  STTS_LAUNCH_PROF("splitk_reduce_kernel", (size_t)work * 4 * 4 * (r.ksplit + 1), splitk_reduce_kernel, dim3((unsigned)std::min<long>(2048, (work + 255) / 256)), dim3(256), st, r.partial,
+                   r.ksplit, r.slice_rows, 0, r.ld_part, r.N, r.bias, r.act, r.R, r.ldr, r.rcol0, r.alpha, p->Y, p->ldy, 0);
+  p->src = SplitSrc{};
+  STTS_HIP(hipGetLastError());
+  return 0;
+}
 struct AdainStats {
   float* in = nullptr;   // statistics of x for norm1 (layout of adain_partial_kernel, round_up(cin, 32) columns)
   bool in_ready = false;
@@ -909,7 +934,10 @@ struct AdainStats {
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
                            float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr,
                            unsigned short* xs16 = nullptr, bool xs16_ready = false, unsigned short* y16 = nullptr, int ldy16 = 0,
-                           AdainStats* stats = nullptr) {
+                           AdainStats* stats = nullptr, PendingReduce* pend_in = nullptr, PendingReduce* pend_out = nullptr) {
+  // pend_in / pend_out (small batches, fold path): x's first columns may still be the split-K partial sums of the contraction that produced them
+  // (pend_in: finished by norm1's statistics launch, which also writes them to x); conv2's own reduce pass is left to the caller's next consumer
+  // (pend_out).  Without them every contraction finishes its own output.
   // stats (16-bit modes, large batches; decoder_forward): statistics written by the producing contractions' epilogues (conv_gemm16_kernel,
   // GemmArgs::stat_part) instead of a pass of adain_partial_kernel per norm - norm1's come from the previous block's conv2 (`in`, if `in_ready`),
   // norm2's from this block's conv1 (`mid`), and conv2 leaves those of y for the next block's norm1 in `out` (`out_ld` columns per row, the
@@ -924,16 +952,24 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   // B = 8 (142 vs 125 us), more than the 11 us pass it removes.
   const bool fold = s.rows() <= 4096;
   STTS_CHECK(ldx >= B.kcin, "adain block: input leading dimension %d < padded channels %d", ldx, B.kcin);
-  auto affine = [&](const float* X, int ld, int C, int ld_aff, int gcol0, float* aff) {
+  auto affine = [&](const float* X, int ld, int C, int ld_aff, int gcol0, float* aff, PendingReduce* pend = nullptr) {
     const int nchunk = ceil_div(ml, kStatChunk), ldp = round_up(C, 32);
+    if (pend && pend->src.partial) {  // the producer's reduce pass rides in the statistics launch (X's first columns are written here)
+      STTS_LAUNCH_PROF("adain_partial_reduce_kernel", (size_t)s.rows() * C * 4 * (1 + pend->src.ksplit), adain_partial_reduce_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st,
+                       const_cast<float*>(X), ld, C, s.dev, ss, ldp, nchunk, pend->src);
+      pend->src = SplitSrc{};
+    } else
     STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ld, C, s.dev, ss, ldp, nchunk);
     STTS_LAUNCH_PROF("adain_affine_kernel", (size_t)s.n_utt * nchunk * 2 * ldp * 4, adain_affine_kernel, dim3(ceil_div(ld_aff, 64), s.n_utt), dim3(64), st, ss, ldp, nchunk, s.dev, style_out, ld_style, gcol0, C,
                        1e-5f, aff, ld_aff);
   };
   // norm1 -> LeakyReLU -> conv1
   GemmArgs a = gemm_args(s);
+  PendingReduce pend_mid;
+  if (pend_in && pend_in->src.partial) STTS_CHECK(pend_in->Y == x && pend_in->ldy == ldx, "adain block: the pending reduce does not belong to this input");
+  if (!fold) STTS_TRY(pending_finish(st, pend_in));
   if (fold) {
-    affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1);
+    affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1, pend_in);
     set_seg(a, 0, x, ldx, 0, B.conv1);
     a.xaff = act1;
     a.ld_xaff = B.kcin;
@@ -965,13 +1001,16 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     if (fuse_stats && gemm16_will_run(a, EPI_STORE, B.conv1.npad, s.n_utt)) {
       a.stat_part = stats->mid; a.ld_stat = round_up(B.cout, 32); a.stat_nchunk = nchunk;
     }
+    SplitInfo info1{};
+    if (fold) a.defer = &info1;  // norm2's statistics launch finishes a split-K conv1
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.conv1.npad, s.n_utt, ml, force_tile));
+    if (fold) pending_from(&pend_mid, info1, a);
   }
   const bool mid_ready = a.stat_part != nullptr;
   // norm2 -> LeakyReLU -> conv2 (+ learned 1x1 shortcut as a second K segment | + identity residual), / sqrt(2)
   GemmArgs b = gemm_args(s);
   if (fold) {
-    affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2);
+    affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2, &pend_mid);
     set_seg(b, 0, hbuf, B.cout, 0, B.conv2);
     b.xaff = act2;
     b.ld_xaff = B.cout;
@@ -1010,7 +1049,10 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
       b.stat_part = stats->out; b.ld_stat = stats->out_ld; b.stat_nchunk = nchunk;
       stats->out_ready = true;
     }
+    SplitInfo info2{};
+    if (fold && pend_out && !y16) b.defer = &info2;  // (a rounded copy of y is cast from y right below: y must exist then)
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.conv2.npad, s.n_utt, ml, force_tile));
+    if (fold && pend_out && !y16) pending_from(pend_out, info2, b);
   }
   if (y16 && !y16_epi) launch_cast_rows(st, B.conv1.prec, y, ldy, B.cout, y16, ldy16, s.rows(), B.cout);  // (cout % 8 == 0: caller)
   STTS_HIP(hipGetLastError());
@@ -1078,7 +1120,10 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   stats.mid = ss_mid;
   stats.out = ss_in;
   stats.out_ld = round_up(ccat, 32);
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat, (x16 && !no_stat_fuse) ? &stats : nullptr));
+  // small batches: a block's conv2 leaves its split-K reduce pass to the next block's first statistics launch (PendingReduce)
+  PendingReduce pend;
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat, (x16 && !no_stat_fuse) ? &stats : nullptr,
+                           nullptr, &pend));
   if (x16) {
     cast_tail(xa, xs16a);
     cast_tail(xb, xs16b);
@@ -1100,11 +1145,11 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     stats.in_ready = stats.out_ready;  // (the previous block's conv2 ran on conv_gemm16_kernel and left the statistics of its output)
     stats.out = i == 4 ? nullptr : ss_in;
     STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat,
-                             (x16 && !no_stat_fuse) ? &stats : nullptr));
+                             (x16 && !no_stat_fuse) ? &stats : nullptr, &pend, &pend));
     std::swap(cur, nxt);
     std::swap(cur16, nxt16);
   }
-  return 0;
+  return pending_finish(st, &pend);  // the last block's output has no AdaIN behind it
 }
 
 #ifdef STTS_WN_TRACE
