@@ -98,6 +98,25 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
   // B operand of the 16x16x32 MFMA from a row tile: lane (row l15, k-group lq) reads 8 consecutive channels of its row
   auto rows_frag = [&](const f32x4* tile, int row, int kstep) { return tile[row * 16 + ((4 * kstep + lq) ^ (row & 15))]; };
 
+  // tail operands (post weights / bias, the coupled half of z): requested inside the LAST layer, when its conv accumulators are dead, so that they
+  // arrive while its res / skip phase runs (requested at the tail they were ~4 us of exposed round trips per block)
+  f32x4 pq[KS][2], pm, ps, zold[RT];
+  const int cc = 16 * w + 4 * lq;
+  auto load_tail = [&]() {
+    const f32x4* w3 = reinterpret_cast<const f32x4*>(a.W3) + (size_t)w * KS * (2 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      pq[t][0] = w3[(t * 2 + 0) * 64];
+      pq[t][1] = w3[(t * 2 + 1) * 64];
+    }
+    pm = *reinterpret_cast<const f32x4*>(a.b3m + cc);
+    ps = *reinterpret_cast<const f32x4*>(a.b3s + cc);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const long g = min(max(rbase + 16 * rt + l15, lo), hi - 1);
+      zold[rt] = *reinterpret_cast<const f32x4*>(a.Z + g * a.ldz + a.zcol0 + cc);
+    }
+  };
   constexpr int T1 = KS * 2 * CT;  // in_layers fragments per tap: 4 k-steps x (tanh, sigmoid) x CT = 16
   constexpr int TH = T1 / 2;       // ... per half tap (2 k-steps): the unit the weight stream runs ahead by
 
@@ -115,19 +134,28 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
     };
     load1(bq[0], 0);
     load1(bq[1], 1);
+    // gate operands of this lane's channels: requested together with the first weights, BEFORE the conv tile is written (every global round trip of
+    // the layer's start is then in flight at once; requested after the LDS pass they cost ~1.5 us per layer, block timeline of round 3)
+    f32x4 ba[CT], bb[CT], ga[CT], gb[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int ch = ch0 + 16 * c;
+      ba[c] = *reinterpret_cast<const f32x4*>(a.b1[l] + ch);
+      ga[c] = *reinterpret_cast<const f32x4*>(a.gate + (long)utt * a.ld_gate + a.gcol0[l] + ch);
+      bb[c] = *reinterpret_cast<const f32x4*>(a.b1[l] + C + ch);
+      gb[c] = *reinterpret_cast<const f32x4*>(a.gate + (long)utt * a.ld_gate + a.gcol0[l] + C + ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- h (rounded) -> conv tile; rows outside the utterance are zero
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int c = 0; c < CT; ++c)
         put4(Hs, PAD + 16 * rt + l15, ch0 + 16 * c, ((in_mask >> rt) & 1) ? hf[(rt * CT + c) * 64] : f32x4{0.f, 0.f, 0.f, 0.f});
-    // gate operands of this lane's channels
-    f32x4 ba[CT], bb[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-      const int ch = ch0 + 16 * c;
-      ba[c] = *reinterpret_cast<const f32x4*>(a.b1[l] + ch) + *reinterpret_cast<const f32x4*>(a.gate + (long)utt * a.ld_gate + a.gcol0[l] + ch);
-      bb[c] = *reinterpret_cast<const f32x4*>(a.b1[l] + C + ch) + *reinterpret_cast<const f32x4*>(a.gate + (long)utt * a.ld_gate + a.gcol0[l] + C + ch);
+      ba[c] += ga[c];
+      bb[c] += gb[c];
     }
     __syncthreads();
 
@@ -195,13 +223,17 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
         f32x4 act;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.885390082f * va[i]) + 1.0f);
-          act[i] = th * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * vb[i]));
+          // tanh(a) sigmoid(b) = (E - 1) / ((E + 1) (1 + F)), E = e^{2a}, F = e^{-b}: two exp2 and ONE rcp (quarter-rate instructions are what
+          // this phase is made of); a is clamped where tanh is 1 in fp32 so that E stays finite
+          const float E = __builtin_amdgcn_exp2f(2.885390082f * fminf(va[i], 15.0f));
+          const float F = __builtin_amdgcn_exp2f(-1.442695041f * vb[i]);
+          act[i] = (E - 1.0f) * __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
         }
         put4(As, 16 * rt + l15, ch0 + 16 * c, act);
       }
     __builtin_amdgcn_sched_barrier(0);  // (the phase-2 operands are fetched once the conv accumulators are dead, not before)
     load2();
+    if constexpr (LAST) load_tail();
     __syncthreads();
 
     // ---- phase 2: res / skip, K = 128 from LDS.  Skip: onto the register accumulator.  Res: the tile of h passes through the registers
@@ -236,21 +268,6 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
   layer(3, std::true_type{});
 
   // ---- tail: post + reverse coupling (+ the next coupling layer's pre); wave w: mean / log-std tiles of channels [16 w, 16 w + 16)
-  const f32x4* w3 = reinterpret_cast<const f32x4*>(a.W3) + (size_t)w * KS * (2 * 64) + lane;
-  f32x4 pq[KS][2];
-#pragma unroll
-  for (int t = 0; t < KS; ++t) {
-    pq[t][0] = w3[(t * 2 + 0) * 64];
-    pq[t][1] = w3[(t * 2 + 1) * 64];
-  }
-  const int cc = 16 * w + 4 * lq;
-  const f32x4 pm = *reinterpret_cast<const f32x4*>(a.b3m + cc), ps = *reinterpret_cast<const f32x4*>(a.b3s + cc);
-  f32x4 zold[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const long g = min(max(rbase + 16 * rt + l15, lo), hi - 1);
-    zold[rt] = *reinterpret_cast<const f32x4*>(a.Z + g * a.ldz + a.zcol0 + cc);
-  }
   __syncthreads();  // every wave has finished reading the gated activations of the last layer
 #pragma unroll
   for (int c = 0; c < CT; ++c)
