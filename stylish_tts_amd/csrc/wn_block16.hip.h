@@ -167,20 +167,28 @@ __global__ void __launch_bounds__(256) wn_block16_kernel(const WnBlock16Args a) 
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[h][c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the B fragments of a step (9 row tiles of the conv tile at one tap / k-step) are fetched one step ahead of the 36 MFMAs that consume them
+    f32x4 avc[RT];
+    auto frags = [&](f32x4(&dst)[RT], int step) {  // step = 2 half + tt = 4 tap + k-step
+      const int tap = step >> 2, t = step & 3;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) dst[rt] = rows_frag(Hs, 16 * rt + l15 + tap, t);  // tile row r + tap - 2 = conv-tile row r + tap
+    };
+    frags(avc, 0);
     auto half_tap = [&](int half, const f32x4(&cur)[TH]) {
-      const int tap = half >> 1;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * (half & 1) + tt;
-        f32x4 av[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) av[rt] = rows_frag(Hs, 16 * rt + l15 + tap, t);  // tile row r + tap - 2 = conv-tile row r + tap
+        const int step = 2 * half + tt;
+        f32x4 avn[RT];
+        frags(avn, min(step + 1, 4 * TAPS - 1));  // (the last step re-reads itself: no branch in the loop body)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[h][c][rt] = mfma16x16<PREC>(cur[(tt * 2 + h) * CT + c], av[rt], acc[h][c][rt]);
+            for (int rt = 0; rt < RT; ++rt) acc[h][c][rt] = mfma16x16<PREC>(cur[(tt * 2 + h) * CT + c], avc[rt], acc[h][c][rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) avc[rt] = avn[rt];
       }
     };
     static_assert(2 * TAPS == 10, "the rolled loop below covers nine half taps in threes + one");
