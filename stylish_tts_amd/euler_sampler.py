@@ -2,9 +2,10 @@
 
 Only the inference side is mirrored (``forward`` / ``solve_euler``); the estimator is any callable with the reference's
 contract ``estimator(x, t=[b], mask=mask, **args) -> dphi/dt`` on device tensors.  The reference's own estimator
-(``CfmMelDecoder._forward``: XUT transformer, HuBERT / wespeaker conditioning) is outside this build, so
-the solver is the part of the denoiser row that can be pinned: time grid and update order are reproduced exactly
-(fp32 ``linspace``, ``t += dt``, ``dt = t_span[step + 1] - t``), the update ``x += dt * v`` runs in the HIP library.
+(``CfmMelDecoder._forward``: XUT transformer on HuBERT / wespeaker features) is ``stylish_tts_amd.cfm_decoder.CfmMelDecoder``
+(``csrc/cfm.hip.h``), whose ``forward`` drives this solver; the solver itself is pinned separately: time grid
+and update order are reproduced exactly (fp32 ``linspace``, ``t += dt``, ``dt = t_span[step + 1] - t``), the update
+``x += dt * v`` runs in the HIP library.
 """
 from __future__ import annotations
 
