@@ -92,6 +92,12 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
     nvirt = gx * (unsigned)__builtin_amdgcn_readfirstlane(tot);
   }
+#ifdef STTS_GEMM_TRACE
+  long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_t = wall_clock64();
+  auto lap = [&](int i) { const long long n = wall_clock64(); tr_acc[i] += n - tr_t; tr_t = n; };
+#else
+  auto lap = [](int) {};
+#endif
   for (unsigned v = blockIdx.x; v < nvirt; v += gridDim.x) {
     int bx, by;
     {
@@ -233,8 +239,10 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
     issue_w(cw, 1, 1, false);
     advance(cw);
     asm volatile("" ::: "memory");
+    lap(1);
     STTS_G16_WAIT_VM(4);  // everything but W(1) has landed (this wave's share; the barrier covers the others') - and the previous tile's stores
     STTS_G16_BARRIER();
+    lap(2);
     if (wr == 1) STTS_G16_BARRIER();  // the second wave group runs one barrier behind the first
     if (ABL & 2) {  // ablation: the fragments are read once, before the loop
       read_x(0, 0, true);
@@ -281,10 +289,12 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
       mma(1, 0);
       STTS_G16_LOOP_BARRIER();
     }
+    lap(3);
     if (wr == 0) STTS_G16_BARRIER();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead DMA of the clamped cursors has landed ...
     STTS_G16_BARRIER();                               // ... in every wave: the next tile's prologue may re-fill the stages
 
+    lap(4);
     // ---- epilogue: acc[tm][tn][e] = output (time row wr*128 + tm*16 + (lane & 15), channel wc*64 + tn*16 + 4*(lane >> 4) + e)
     const int nvalid = len - rel0;
     const bool hasR = a.R != nullptr, hasY = a.Y != nullptr, hasY16 = a.Y16 != nullptr, hasSS = a.sumsq_part != nullptr;
@@ -304,36 +314,87 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
       nok[tn] = n < a.N;  // N is a multiple of 4 (launcher)
     }
     float* const Yb = hasY ? a.Y + (long)row0 * a.ldy + a.ycol0 + m0 + cl : nullptr;
-    const float* const Rb = hasR ? a.R + (long)row0 * a.ldr + a.rcol0 + m0 + cl : nullptr;
+    // residual rows through a buffer descriptor over this tile's valid rows (rows past them read as zeros and are not stored), fetched ONE ROW TILE
+    // AHEAD of their use: with the load inside the guarded store block every one of the 32 accumulator tiles waited for its own round trip
+    // (pwconv2: 29 us of epilogue per 256 x 256 tile, block timeline of round 3)
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(hasR ? a.R + (long)row0 * a.ldr + a.rcol0 + m0 : a.zeros), 0, hasR ? (unsigned)(((long)(nvalid < kG16Tile ? nvalid : kG16Tile) * a.ldr) * 4) : 0u, 0x00020000);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    f32x4 rnext[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto load_r = [&](int tm) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) rnext[tn] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rr, ((tl + tm * 16) * a.ldr + cl + tn * 16) * 4, 0, 0));
+    };
+    if (!MSEG && hasR) load_r(0);
+    const float* const Rb = hasR ? a.R + (long)row0 * a.ldr + a.rcol0 + m0 + cl : nullptr;  // (multi-segment kernels: the residual is read where it is used)
     unsigned short* const Y16b = hasY16 ? a.Y16 + (long)row0 * a.ldy16 + a.ycol16 + m0 + cl : nullptr;
     const bool hasST = a.stat_part != nullptr;
     f32x4 ss[4], su[4];
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) ss[tn] = su[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The unrolled 8 x 4 store loop, SPECIALISED at compile time on what this launch's epilogue does: with `act`, `R`, `Y` and `Y16` as run-time
+    // values the loop body carried ~1 300 scalar branches per tile (the activation switch per element, the output / residual tests per accumulator
+    // tile) - 10-14 us of epilogue per 256 x 256 tile, as much as a short K loop (block timeline of round 3).
+    auto store_loop = [&](auto gen_c, auto silu_c, auto hr_c, auto hy_c, auto hy16_c) {
+      constexpr bool GEN = decltype(gen_c)::value;  // generic body: everything decided at run time
+      constexpr bool SILU = decltype(silu_c)::value;
+      const bool HR = GEN ? hasR : decltype(hr_c)::value, HY = GEN ? hasY : decltype(hy_c)::value, HY16 = GEN ? hasY16 : decltype(hy16_c)::value;
 #pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-      const int tr = tl + tm * 16;
-      const bool rok = tr < nvalid;
+      for (int tm = 0; tm < 8; ++tm) {
+        const int tr = tl + tm * 16;
+        const bool rok = tr < nvalid;
+        f32x4 rcur[4];
+        if constexpr (!MSEG) {
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        f32x4 vv = acc[tm][tn] + bv[tn];
+          for (int tn = 0; tn < 4; ++tn) rcur[tn] = rnext[tn];
+          if (HR && tm + 1 < 8) load_r(tm + 1);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], act);
-        if (rok && nok[tn]) {
-          if (hasR) vv += *reinterpret_cast<const f32x4*>(Rb + (unsigned)(tr * a.ldr + tn * 16));
-          vv *= alpha;
-          if (hasY && !((ABL & 8) && vv[0] != 12345.f)) {
-            if (ABL & 64) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)));
-            else *reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)) = vv;
+        for (int tn = 0; tn < 4; ++tn) {
+          f32x4 vv = acc[tm][tn] + bv[tn];
+          if constexpr (GEN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], act);
+          } else if constexpr (SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], ACT_SILU);
           }
-          if (hasY16 && !((ABL & 8) && vv[0] != 12345.f)) {
-            if (ABL & 64) __builtin_nontemporal_store(pack4_16<PREC>(vv), reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)));
-            else *reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)) = pack4_16<PREC>(vv);
+          if (rok && nok[tn]) {
+            if constexpr (MSEG) {
+              if (HR) vv += *reinterpret_cast<const f32x4*>(Rb + (unsigned)(tr * a.ldr + tn * 16));
+            } else {
+              if (HR) vv += rcur[tn];
+            }
+            vv *= alpha;
+            if (HY && !((ABL & 8) && vv[0] != 12345.f)) {
+              if (ABL & 64) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)));
+              else *reinterpret_cast<f32x4*>(Yb + (unsigned)(tr * a.ldy + tn * 16)) = vv;
+            }
+            if (HY16 && !((ABL & 8) && vv[0] != 12345.f)) {
+              if (ABL & 64) __builtin_nontemporal_store(pack4_16<PREC>(vv), reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)));
+              else *reinterpret_cast<u32x2*>(Y16b + (unsigned)(tr * a.ldy16 + tn * 16)) = pack4_16<PREC>(vv);
+            }
+            ss[tn] += vv * vv;
+            su[tn] += vv;
           }
-          ss[tn] += vv * vv;
-          su[tn] += vv;
         }
       }
+    };
+    {
+      using T = std::true_type;
+      using F = std::false_type;
+      bool done = false;
+      // (single-segment kernels only: in the multi-segment kernel the extra bodies cost registers - 230 -> 256 + spills inside the K loop, conv2 + shortcut 165 -> 245 us)
+      if (ABL == 0 && !MSEG && !(a.tune & 0x4000)) {  // (tune bit 0x4000, STTS_G16_GENERIC=1: A/B switch for the generic body)  the five combinations the 16-bit frame path launches; anything else (and the probe's ablation builds): the generic body
+        done = true;
+        if (act == ACT_SILU && !hasR && !hasY && hasY16) store_loop(F{}, T{}, F{}, F{}, T{});       // pwconv1: SiLU -> 16-bit rows (+ GRN sums)
+        else if (act == ACT_NONE && !hasR && hasY && !hasY16) store_loop(F{}, F{}, F{}, T{}, F{});  // fp32 rows: conv1, projector, output convs
+        else if (act == ACT_NONE && hasR && hasY && !hasY16) store_loop(F{}, F{}, T{}, T{}, F{});   // pwconv2: + residual
+        else if (act == ACT_NONE && !hasR && hasY && hasY16) store_loop(F{}, F{}, F{}, T{}, T{});   // conv2 + shortcut: fp32 rows and their rounded copy
+        else if (act == ACT_NONE && !hasR && !hasY && hasY16) store_loop(F{}, F{}, F{}, F{}, T{});  // 16-bit rows only (prior convs)
+        else done = false;
+      }
+      if (!done) store_loop(T{}, F{}, F{}, F{}, F{});
     }
     if (hasST) {
       // AdaIN statistics of this wave's 128 rows = chunk 2 local + wr of the utterance (adain_partial_kernel's chunks are 128 rows from the
@@ -381,7 +442,15 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
         }
       }
     }
+    lap(5);
+#ifdef STTS_GEMM_TRACE
+    ++tr_acc[0];
+#endif
   }
+#ifdef STTS_GEMM_TRACE
+  if (a.dbg && tid == 0)
+    for (int i = 0; i < 6; ++i) a.dbg[8 * (long)blockIdx.x + i] = tr_acc[i];
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -418,6 +487,8 @@ inline int launch_conv_gemm16(hipStream_t st, const GemmArgs& a, int npad, int n
   as.tiles_y = (int)rt;
   as.ksplit = 1;
   as.gemm16_gx = npad / kG16Tile;
+  static const bool force_generic = getenv("STTS_G16_GENERIC") != nullptr;
+  if (force_generic) as.tune |= 0x4000;
   GemmProfiler& prof = gemm_profiler();
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof.on) {

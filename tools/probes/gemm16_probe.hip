@@ -105,6 +105,12 @@ static int run(int n_utt, int rows_per_utt, int cin, int cout, int k, bool check
     a.seg[1].ntaps = 1; a.seg[1].dil = 1; a.seg[1].pad = 0; a.seg[1].kreal = cin2;
   }
   a.x16 = 1;
+#ifdef STTS_GEMM_TRACE
+  long long* dbg = nullptr;
+  STTS_HIP(hipMalloc(&dbg, 8 * 8 * 256));
+  STTS_HIP(hipMemset(dbg, 0, 8 * 8 * 256));
+  a.dbg = dbg;
+#endif
   a.N = cout; a.bias = B; a.alpha = 0.5f;
   unsigned short* Y16 = nullptr;
   float* part = nullptr;
@@ -172,6 +178,19 @@ static int run(int n_utt, int rows_per_utt, int cin, int cout, int k, bool check
         STTS_HIP(hipEventElapsedTime(&ms, e0, e1));
         t[v].push_back(ms / iters);
       }
+#ifdef STTS_GEMM_TRACE
+    {
+      STTS_TRY(go(0));
+      STTS_HIP(hipStreamSynchronize(st));
+      std::vector<long long> h(8 * 256);
+      STTS_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      double s[6] = {};
+      for (int b = 0; b < 256; ++b)
+        for (int i = 0; i < 6; ++i) s[i] += (double)h[8 * b + i] / 256.0;
+      printf("%-11s block timeline (averages over 256 blocks, us per block): tiles %.2f | lookup + prologue issue %.1f | prologue wait %.1f | K loop %.1f | loop-end drain %.1f | epilogue %.1f\n", name,
+             s[0], s[1] * 0.01, s[2] * 0.01, s[3] * 0.01, s[4] * 0.01, s[5] * 0.01);
+    }
+#endif
     for (int v = 0; v < n_abl; ++v) {
       std::sort(t[v].begin(), t[v].end());
       const float mn = t[v][0], md = t[v][rounds / 2];
