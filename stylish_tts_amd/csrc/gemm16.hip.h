@@ -384,15 +384,21 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
       using T = std::true_type;
       using F = std::false_type;
       bool done = false;
-      // (single-segment kernels only: in the multi-segment kernel the extra bodies cost registers - 230 -> 256 + spills inside the K loop, conv2 + shortcut 165 -> 245 us)
-      if (ABL == 0 && !MSEG && !(a.tune & 0x4000)) {  // (tune bit 0x4000, STTS_G16_GENERIC=1: A/B switch for the generic body)  the five combinations the 16-bit frame path launches; anything else (and the probe's ablation builds): the generic body
+      // (the multi-segment kernel gets only its own two: with all five bodies it went from 230 to 256 registers + spills inside the K loop,
+      //  conv2 + shortcut 165 -> 245 us)
+      if (ABL == 0 && !(a.tune & 0x4000)) {  // (tune bit 0x4000, STTS_G16_GENERIC=1: A/B switch for the generic body)
         done = true;
-        if (act == ACT_SILU && !hasR && !hasY && hasY16) store_loop(F{}, T{}, F{}, F{}, T{});       // pwconv1: SiLU -> 16-bit rows (+ GRN sums)
-        else if (act == ACT_NONE && !hasR && hasY && !hasY16) store_loop(F{}, F{}, F{}, T{}, F{});  // fp32 rows: conv1, projector, output convs
-        else if (act == ACT_NONE && hasR && hasY && !hasY16) store_loop(F{}, F{}, T{}, T{}, F{});   // pwconv2: + residual
-        else if (act == ACT_NONE && !hasR && hasY && hasY16) store_loop(F{}, F{}, F{}, T{}, T{});   // conv2 + shortcut: fp32 rows and their rounded copy
-        else if (act == ACT_NONE && !hasR && !hasY && hasY16) store_loop(F{}, F{}, F{}, F{}, T{});  // 16-bit rows only (prior convs)
-        else done = false;
+        if constexpr (MSEG) {
+          if (act == ACT_NONE && !hasR && hasY && hasY16) store_loop(F{}, F{}, F{}, T{}, T{});        // conv2 + shortcut: fp32 rows and their rounded copy
+          else if (act == ACT_NONE && !hasR && hasY && !hasY16) store_loop(F{}, F{}, F{}, T{}, F{});  // projector
+          else done = false;
+        } else {
+          if (act == ACT_SILU && !hasR && !hasY && hasY16) store_loop(F{}, T{}, F{}, F{}, T{});       // pwconv1: SiLU -> 16-bit rows (+ GRN sums)
+          else if (act == ACT_NONE && !hasR && hasY && !hasY16) store_loop(F{}, F{}, F{}, T{}, F{});  // fp32 rows: conv1, output convs
+          else if (act == ACT_NONE && hasR && hasY && !hasY16) store_loop(F{}, F{}, T{}, T{}, F{});   // pwconv2: + residual
+          else if (act == ACT_NONE && !hasR && !hasY && hasY16) store_loop(F{}, F{}, F{}, F{}, T{});  // 16-bit rows only (prior convs)
+          else done = false;
+        }
       }
       if (!done) store_loop(T{}, F{}, F{}, F{}, F{});
     }
