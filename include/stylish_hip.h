@@ -184,7 +184,7 @@ int stts_duration_to_alignment(void* stream, const int32_t* dur, int n_tokens, i
  * time-major gather of the phoneme encoding at rate rep (1: mel frames, 4: vocoder frames).
  * dur [n_tok] int32 (device), tok_off [n_utt+1], frm_off [n_utt+1] (= rep * cumulative durations), both device.
  * enc [n_tok, ld_enc] -> out [frames, ld_out] columns [0, C).  Any number of tokens per utterance (the durations are
- * scanned in chunks); limits elsewhere: attention with heads other than 32 / 64 / 96 / 128 channels takes at most 1024 keys per utterance (the
+ * scanned in chunks); limits elsewhere: attention with heads other than 16 / 32 / 40 / 64 / 96 / 128 / 160 channels takes at most 1024 keys per utterance (the
  * reference's own limit is 510 tokens, train/dataloader.py:106-109; those head sizes run on the matrix-core kernel, which streams
  * the keys and has no limit) and stts_duration_to_alignment at most 1024 tokens. */
 int stts_length_regulate(stts_ctx* ctx, void* stream, int n_utt, const int32_t* dur, const int32_t* tok_off, const int32_t* frm_off,
@@ -204,7 +204,7 @@ int stts_euler_step(void* stream, float* x, const float* v, float dt, int64_t n)
  * columns finite), f0 / n_curve: per-utterance curves back to back with offsets curve_off (resampled to the utterance's frames by
  * F.interpolate's nearest rule, :322-323), spk_emb [n_utt, spk_dim], t [n_utt], sine_noise [rows] = the one RNG draw inside the
  * estimator (SineGenerator's additive noise, :99; the caller draws it), out [rows, ld_out] = dphi/dt.  All tensors on the device.
- * Limits: head_dim 32 / 64 (the class default) / 96 / 128 for utterances beyond 1024 frames - other head sizes keep an utterance's
+ * Limits: head_dim 16 / 32 / 40 / 64 (the class default) / 96 / 128 / 160 for utterances beyond 1024 frames - other head sizes keep an utterance's
  * attention scores in LDS (<= 1024 keys); SineGenerator without overtones (the reference's configuration). */
 typedef struct stts_cfm_dims {
   int32_t feat_dim, asr_dim, spk_dim, hidden_dim, emb_dim, depth, enc_blocks, dec_blocks, prev_depth, post_depth, head_dim;
@@ -265,7 +265,7 @@ int stts_op_adain_block(stts_ctx* ctx, void* stream, const char* prefix, int n_u
  * models/xut/attention.py): q [q rows, heads * kc], k / v [k rows, heads * kc], o [q rows, heads * kc]; utterance u's queries see its
  * own keys only.  band_centre (optional, [q rows] int32) + window: the pitch/energy predictor's inverted band mask.
  * kernel: 0 = the stage's own choice, 1 = one wave per four queries (attention_kernel), 2 = matrix cores (attention_mfma_kernel,
- * kc 32 / 64 / 96 / 128). */
+ * kc 16 / 32 / 40 / 64 / 96 / 128 / 160). */
 int stts_op_attention(void* stream, int n_utt, const int32_t* q_off_host, const int32_t* q_off_dev, const int32_t* k_off_host,
                       const int32_t* k_off_dev, const float* q, const float* k, const float* v, float* o, int heads, int kc,
                       const int32_t* band_centre, int window, int kernel);

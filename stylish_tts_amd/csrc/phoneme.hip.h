@@ -138,8 +138,8 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same attention on the matrix cores, for heads of KC = 32 / 64 / 96 / 128 channels (the text encoders: 2 heads x 96; the
-// flow-matching decoder's XUT blocks: heads of 64, 240-800 frames, models/xut/attention.py) - flash-style: a block = 128 queries of one
+// The same attention on the matrix cores, for heads of KC = 16 / 32 / 40 / 64 / 96 / 128 / 160 channels (the text encoders: 8 heads x 16; the predictors' prosody
+// encoders: 2 x 96 and 2 x 160; the pitch / energy cross-attention: 8 x 40; the flow-matching decoder's XUT blocks: heads of 64, 240-800 frames, models/xut/attention.py) - flash-style: a block = 128 queries of one
 // (utterance, head), one wave per 32 queries, the keys / values stream through LDS in blocks of 32 (double buffered, one barrier per
 // block), softmax is kept as a running maximum and sum per query (the exact softmax of attention_kernel up to fp32 rounding: ~1e-7
 // relative), any number of keys.  v_mfma_f32_32x32x2_f32, fp32 throughout.  Both products are taken TRANSPOSED so that a lane owns one query:
@@ -152,14 +152,16 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
 // V rows KC + 8 (the two half-waves read keys 4 rows apart: 4 (KC + 8) = 32 mod 64, opposite bank halves).
 // ---------------------------------------------------------------------------------------------
 constexpr int kAttnMfmaQ = 128;
-inline bool attn_mfma_kc(int kc) { return kc == 32 || kc == 64 || kc == 96 || kc == 128; }
+inline bool attn_mfma_kc(int kc) { return kc == 16 || kc == 32 || kc == 40 || kc == 64 || kc == 96 || kc == 128 || kc == 160; }
 template <int KC>
 __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
                                                              int kcol0, const float* __restrict__ V, int ldv, int vcol0, float* __restrict__ O, int ldo,
                                                              const int* __restrict__ q_off, const int* __restrict__ k_off,
                                                              const int* __restrict__ band_centre, int window, float scale) {
-  static_assert(KC % 32 == 0 && KC <= 128, "head size");
-  constexpr int KS = KC + 2, VS = KC + 8, G = KC / 4, NE = KC / 32;  // row strides (floats), float4 groups per row, staged float4 per thread and matrix
+  static_assert(KC % 8 == 0 && KC <= 160, "head size");
+  // KCP: the head size padded to whole 32-channel output tiles (the text encoders' heads of 16 and the predictors' heads of 40 / 160 channels: the
+  // pad columns of the V stage are zeros, written once); row strides (floats): K rows KC + 2, V rows KCP + 8; G float4 groups per staged row
+  constexpr int KCP = (KC + 31) / 32 * 32, NT = KCP / 32, KS = KC + 2, VS = KCP + 8, G = KC / 4, NE = (32 * G + 255) / 256;
   __shared__ float Ks[2][32 * KS];
   __shared__ f32x4 Vs[2][32 * VS / 4];
   const int u = blockIdx.z, h = blockIdx.y;
@@ -175,10 +177,16 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
 #pragma unroll
     for (int s = 0; s < KC / 2; ++s) qf[s] = qp[2 * s];
   }
+  if constexpr (KCP > KC) {  // zero pad columns of both V stages (the staging below writes the real columns only)
+    for (int i = tid; i < 2 * 32 * (KCP - KC) / 4; i += 256) {
+      const int b = i / (32 * (KCP - KC) / 4), j = i % (32 * (KCP - KC) / 4), r = j / ((KCP - KC) / 4), g = j % ((KCP - KC) / 4);
+      Vs[b][r * (VS / 4) + G + g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   const int centre = band_centre ? band_centre[qlo + ql] : 0;
-  f32x16 o[KC / 32];
+  f32x16 o[NT];
 #pragma unroll
-  for (int t = 0; t < KC / 32; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float m = -INFINITY, lsum = 0.f;
@@ -188,7 +196,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
   auto gfetch = [&](int kb) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-      const int idx = tid + 256 * e, r = idx / G, g = idx % G;
+      const int idx = tid + 256 * e, r = min(idx / G, 31), g = idx % G;
       const int j = kb * 32 + r;
       const bool ok = j < nk;
       const long row = klo + min(j, nk - 1);
@@ -203,6 +211,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int idx = tid + 256 * e, r = idx / G, g = idx % G;
+      if (32 * G % 256 != 0 && idx >= 32 * G) continue;  // (heads whose 32 x KC block is not a multiple of 256 float4s)
       float2* kd = reinterpret_cast<float2*>(&Ks[buf][r * KS + 4 * g]);  // (rows are 8-byte aligned: KS is even)
       kd[0] = make_float2(kreg[e].x, kreg[e].y);
       kd[1] = make_float2(kreg[e].z, kreg[e].w);
@@ -247,12 +256,12 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
     lsum = lsum * resc + psum;
     m = mnew;
 #pragma unroll
-    for (int t = 0; t < KC / 32; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[t][i] *= resc;
     // ---- O^T += V^T P^T
 #pragma unroll
-    for (int t = 0; t < KC / 32; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = 8 * (i >> 2) + 4 * lh + (i & 3);
@@ -263,11 +272,13 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
     const float inv = 1.0f / lsum;
     float* op = O + (long)(qlo + q0 + l31) * ldo + h * KC + 4 * lh;
 #pragma unroll
-    for (int t = 0; t < KC / 32; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
-        const f32x4 v = {o[t][4 * i4] * inv, o[t][4 * i4 + 1] * inv, o[t][4 * i4 + 2] * inv, o[t][4 * i4 + 3] * inv};
-        *reinterpret_cast<f32x4*>(op + 32 * t + 8 * i4) = v;  // channels 32 t + 8 i4 + 4 lh + (0..3)
+        if (32 * t + 8 * i4 + 4 * lh < KC) {  // (KC is a multiple of 8: a lane's four channels are all real or all pad)
+          const f32x4 v = {o[t][4 * i4] * inv, o[t][4 * i4 + 1] * inv, o[t][4 * i4 + 2] * inv, o[t][4 * i4 + 3] * inv};
+          *reinterpret_cast<f32x4*>(op + 32 * t + 8 * i4) = v;  // channels 32 t + 8 i4 + 4 lh + (0..3)
+        }
       }
   }
 }

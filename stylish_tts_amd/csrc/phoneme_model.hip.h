@@ -281,19 +281,22 @@ inline int gemm_ln(hipStream_t st, const Seg& s, const float* X, int ldx, const 
 inline int run_attention(hipStream_t st, const Seg& sq, const Seg& sk, const float* Q, int ldq, int qcol0, const float* K, int ldk, int kcol0,
                          const float* V, int ldv, int vcol0, float* O, int ldo, int heads, int kc, const int* band_centre, int window, int force_kernel = 0) {
   STTS_CHECK(kc <= kAttnMaxKc && kc % 4 == 0, "attention: head size %d unsupported", kc);
-  // heads of 32 / 64 / 96 / 128 channels: the matrix-core kernel, whatever the lengths (any number of keys) - the choice must not depend on the
+  // heads of 16 / 32 / 40 / 64 / 96 / 128 / 160 channels: the matrix-core kernel, whatever the lengths (any number of keys) - the choice must not depend on the
   // batch, so that an utterance's result is the same alone and packed with others; other head sizes: one wave per 4 queries
   static const int mfma_min = getenv("STTS_ATTN_MFMA_MIN") ? atoi(getenv("STTS_ATTN_MFMA_MIN")) : 0;  // (experiments: shortest sequence for the matrix-core kernel)
   const bool aligned = ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && qcol0 % 4 == 0 && kcol0 % 4 == 0 && vcol0 % 4 == 0;
-  STTS_CHECK(force_kernel != 2 || (attn_mfma_kc(kc) && aligned), "attention: the matrix-core kernel needs heads of 32 / 64 / 96 / 128 channels and 16-byte aligned rows");
+  STTS_CHECK(force_kernel != 2 || (attn_mfma_kc(kc) && aligned), "attention: the matrix-core kernel needs heads of 16 / 32 / 40 / 64 / 96 / 128 / 160 channels and 16-byte aligned rows");
   if (force_kernel == 2 || (force_kernel == 0 && attn_mfma_kc(kc) && aligned && sq.max_len() >= mfma_min && sk.max_len() >= mfma_min)) {
     const dim3 grid(ceil_div(sq.max_len(), kAttnMfmaQ), heads, sq.n_utt);
     const float scale = 1.0f / sqrtf((float)kc);
 #define STTS_ATTN(KCV) hipLaunchKernelGGL(attention_mfma_kernel<KCV>, grid, dim3(256), 0, st, Q, ldq, qcol0, K, ldk, kcol0, V, ldv, vcol0, O, ldo, sq.dev, sk.dev, band_centre, window, scale)
-    if (kc == 32) STTS_ATTN(32);
+    if (kc == 16) STTS_ATTN(16);
+    else if (kc == 32) STTS_ATTN(32);
+    else if (kc == 40) STTS_ATTN(40);
     else if (kc == 64) STTS_ATTN(64);
     else if (kc == 96) STTS_ATTN(96);
-    else STTS_ATTN(128);
+    else if (kc == 128) STTS_ATTN(128);
+    else STTS_ATTN(160);
 #undef STTS_ATTN
     STTS_HIP(hipGetLastError());
     return 0;

@@ -115,10 +115,10 @@ def test_matrix_core_attention_beyond_1024_keys(hip):
         hip.op_attention(segs(lens), segs(lens), dev(q), dev(k), dev(v), heads, kc, kernel=1)
 
 
-@pytest.mark.parametrize("kc", [32, 96, 128])
+@pytest.mark.parametrize("kc", [16, 32, 40, 96, 128, 160])
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_other_matrix_core_head_sizes(hip, kc, kernel):
-    """Heads of 32 / 96 / 128 channels (the text encoders run 2 x 96) on both kernels."""
+    """The other matrix-core head sizes (text encoders: 8 x 16, prosody encoders: 2 x 96 / 2 x 160, pitch / energy cross-attention: 8 x 40) on both kernels."""
     heads = 2
     q_lens, k_lens = [50, 130, 7, 257], [50, 130, 40, 100]
     q, k, v = make(f"att.kc{kc}", q_lens, k_lens, heads, kc, spread=1.5)
@@ -136,5 +136,5 @@ def test_other_head_sizes_stay_on_the_wave_kernel(hip):
     want = reference(q, k, v, lens, lens, heads, kc)
     got = hip.op_attention(segs(lens), segs(lens), dev(q), dev(k), dev(v), heads, kc).cpu().numpy()
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-6
-    with pytest.raises(RuntimeError, match="matrix-core kernel needs heads of 32 / 64 / 96 / 128"):
+    with pytest.raises(RuntimeError, match="matrix-core kernel needs heads of 16 / 32 / 40 / 64 / 96 / 128 / 160"):
         hip.op_attention(segs(lens), segs(lens), dev(q), dev(k), dev(v), heads, kc, kernel=2)
