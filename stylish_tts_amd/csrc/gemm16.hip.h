@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-descriptor type and builtins exist on the device side only: the host pass sees an empty body)
   // ALL of the block's LDS is this one array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt before
   // every fragment read): 2 stages x [X0 | X1 | W0 | W1] x 128 rows x 8 slots of 16 bytes = 128 KB
-  __shared__ f32x4 lds[2 * 4 * 1024];
+  __shared__ f32x4 lds[2 * 4 * 1024 + 64];  // (+ 1 KB behind the stages: the block's tile directory, below)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wv >> 2, wc = wv & 3;  // time half / cout quarter of this wave; waves w and w + 4 share a SIMD
@@ -92,6 +92,26 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
     nvirt = gx * (unsigned)__builtin_amdgcn_readfirstlane(tot);
   }
+  // Tile directory (batches of up to 64 utterances): lane u's exclusive / inclusive prefix of 256-row tiles, first row and length, computed ONCE per
+  // block and parked in LDS - per tile the lookup is then a ballot and three LDS reads instead of two global loads, a 6-step scan and two dependent
+  // scalar loads (~1.5 us per tile in the block timeline: as much as a K tile).
+  const bool dir_ok = a.n_utt <= 64;
+  int* const dir = reinterpret_cast<int*>(lds + 2 * 4 * 1024);  // [4][64]: excl, incl, lo, len
+  if (dir_ok && wv == 0) {
+    const int lo_u = lane < a.n_utt ? a.seg_off[lane] : 0, len_u = lane < a.n_utt ? a.seg_off[lane + 1] - lo_u : 0;
+    const int tiles = (len_u + kG16Tile - 1) / kG16Tile;
+    int incl = tiles;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int vv = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += vv;
+    }
+    dir[lane] = incl - tiles;
+    dir[64 + lane] = incl;
+    dir[128 + lane] = lo_u;
+    dir[192 + lane] = len_u;
+  }
+  if (dir_ok) __syncthreads();
 #ifdef STTS_GEMM_TRACE
   long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_t = wall_clock64();
   auto lap = [&](int i) { const long long n = wall_clock64(); tr_acc[i] += n - tr_t; tr_t = n; };
@@ -106,8 +126,19 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
       bx = id % gx;
       by = id / gx;
     }
-    int utt = -1, local = 0;
-    {
+    int utt = -1, local = 0, dir_lo = 0, dir_len = 0;
+    if (dir_ok) {
+      const int t = by + a.tile0;
+      const int excl = dir[lane], incl = dir[64 + lane];
+      const unsigned long long hit = __ballot(t >= excl && t < incl);
+      if (hit) {
+        const int src = __ffsll((long long)hit) - 1;
+        utt = src;
+        local = t - dir[src];
+        dir_lo = dir[128 + src];
+        dir_len = dir[192 + src];
+      }
+    } else {
       const int t = by + a.tile0;
       int base = 0;
       for (int u0 = 0; u0 < a.n_utt && utt < 0; u0 += 64) {
@@ -132,8 +163,9 @@ __global__ void __launch_bounds__(512, 2) conv_gemm16_kernel(const GemmArgs a) {
     if (utt < 0) continue;  // a row tile beyond the batch's last one (the host grid is an upper bound when the offsets live on the device)
     utt = __builtin_amdgcn_readfirstlane(utt);
     local = __builtin_amdgcn_readfirstlane(local);
-    const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
-    const int len = hi - lo, rel0 = local * kG16Tile;
+    const int lo = dir_ok ? __builtin_amdgcn_readfirstlane(dir_lo) : a.seg_off[utt];
+    const int len = dir_ok ? __builtin_amdgcn_readfirstlane(dir_len) : a.seg_off[utt + 1] - lo;
+    const int hi = lo + len, rel0 = local * kG16Tile;
     const int row0 = lo + rel0;
     if (rel0 >= len) continue;
     const int m0 = bx * kG16Tile;
