@@ -67,6 +67,8 @@ struct GemmArgs {
   const int* seg_host;  // the same offsets on the host (launcher only): exact tile counts for mixed-length batches
   int n_utt;
   int compact;          // grid.y enumerates only the row tiles that exist (sum over utterances), grid.z = split-K slice
+  int uniform_len, uniform_lo0;  // > 0: every utterance has this many rows, the first starts at row uniform_lo0 (host side knows: the tile lookup is then
+                        // a division - no offset loads, no scan; equal-length batches, B = 1, the planes of a Winograd-form conv)
   int tile0, tiles_y;   // compact: this launch covers global row tiles [tile0, tile0 + tiles_y)
   int gemm16_gx;        // conv_gemm16_kernel (persistent blocks): cout tiles of the virtual grid
   int capacity;         // seg_host holds UPPER BOUNDS of the utterance lengths (the real offsets live only on the device): grids are sized from
@@ -229,7 +231,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     utt = a.n_utt - 1;
     int base = 0, local = 0;
     bool done = false;
-    for (int u0 = 0; u0 < a.n_utt && !done; u0 += 64) {
+    if (a.uniform_len > 0) {
+      const int tpu = (a.uniform_len + BN - 1) / BN;
+      utt = t / tpu;
+      local = t - utt * tpu;
+      done = utt < a.n_utt;
+    }
+    for (int u0 = 0; u0 < a.n_utt && !done && a.uniform_len <= 0; u0 += 64) {
       const int u = u0 + lane_;
       const int tiles = u < a.n_utt ? (a.seg_off[u + 1] - a.seg_off[u] + BN - 1) / BN : 0;
       int incl = tiles;
@@ -254,7 +262,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     utt = bz / ksplit;
     ks = bz % ksplit;
   }
-  const int lo = a.seg_off[utt], hi = a.seg_off[utt + 1];
+  const int lo = a.uniform_len > 0 ? a.uniform_lo0 + utt * a.uniform_len : a.seg_off[utt];
+  const int hi = a.uniform_len > 0 ? lo + a.uniform_len : a.seg_off[utt + 1];
   const int row0 = lo + by * BN;
   if (row0 >= hi) return;
   const int m0 = bx * BM;

@@ -757,6 +757,12 @@ inline GemmArgs gemm_args(const Seg& s) {
   a.n_utt = s.n_utt;
   a.rows_total = s.rows();
   a.capacity = s.cap;
+  if (!s.cap && s.host && s.n_utt > 0) {  // equal lengths (known on the host): the kernels' tile lookup is arithmetic
+    const int len = s.host[1] - s.host[0];
+    bool same = len > 0;
+    for (int u = 1; u < s.n_utt && same; ++u) same = s.host[u + 1] - s.host[u] == len;
+    if (same) { a.uniform_len = len; a.uniform_lo0 = s.host[0]; }
+  }
   a.alpha = 1.0f;
   a.zeros = zero_page();
   return a;
