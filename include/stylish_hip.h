@@ -265,7 +265,7 @@ int stts_op_adain_block(stts_ctx* ctx, void* stream, const char* prefix, int n_u
  * models/xut/attention.py): q [q rows, heads * kc], k / v [k rows, heads * kc], o [q rows, heads * kc]; utterance u's queries see its
  * own keys only.  band_centre (optional, [q rows] int32) + window: the pitch/energy predictor's inverted band mask.
  * kernel: 0 = the stage's own choice, 1 = one wave per four queries (attention_kernel), 2 = matrix cores (attention_mfma_kernel,
- * kc 16 / 32 / 40 / 64 / 96 / 128 / 160). */
+ * kc 16 / 32 / 40 / 64 / 96 / 128 / 160; heads of 64 split the keys over two wave groups from 128 keys on), 3 = matrix cores, never split. */
 int stts_op_attention(void* stream, int n_utt, const int32_t* q_off_host, const int32_t* q_off_dev, const int32_t* k_off_host,
                       const int32_t* k_off_dev, const float* q, const float* k, const float* v, float* o, int heads, int kc,
                       const int32_t* band_centre, int window, int kernel);

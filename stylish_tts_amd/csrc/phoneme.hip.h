@@ -153,8 +153,11 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int kAttnMfmaQ = 128;
 inline bool attn_mfma_kc(int kc) { return kc == 16 || kc == 32 || kc == 40 || kc == 64 || kc == 96 || kc == 128 || kc == 160; }
-template <int KC>
-__global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
+// SPLIT = 2 (long sequences): two wave groups per query tile take the even / odd key blocks, each with its own running maximum / sum / accumulator,
+// merged through LDS at the end - a problem of 8 x 800 frames x 4 heads is 896 wave tiles for 1 024 SIMDs, i.e. less than one wave per SIMD, and a wave
+// alone on its SIMD alternates dependent MFMA chains with the softmax's vector work; with the keys split the SIMDs hold two waves that interleave.
+template <int KC, int SPLIT = 1>
+__global__ void __launch_bounds__(256 * SPLIT) attention_mfma_kernel(const float* __restrict__ Q, int ldq, int qcol0, const float* __restrict__ K, int ldk,
                                                              int kcol0, const float* __restrict__ V, int ldv, int vcol0, float* __restrict__ O, int ldo,
                                                              const int* __restrict__ q_off, const int* __restrict__ k_off,
                                                              const int* __restrict__ band_centre, int window, float scale) {
@@ -162,13 +165,15 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
   // KCP: the head size padded to whole 32-channel output tiles (the text encoders' heads of 16 and the predictors' heads of 40 / 160 channels: the
   // pad columns of the V stage are zeros, written once); row strides (floats): K rows KC + 2, V rows KCP + 8; G float4 groups per staged row
   constexpr int KCP = (KC + 31) / 32 * 32, NT = KCP / 32, KS = KC + 2, VS = KCP + 8, G = KC / 4, NE = (32 * G + 255) / 256;
-  __shared__ float Ks[2][32 * KS];
-  __shared__ f32x4 Vs[2][32 * VS / 4];
+  static_assert(SPLIT == 1 || SPLIT == 2, "key split");
+  __shared__ float Ks[2][SPLIT][32 * KS];
+  __shared__ f32x4 Vs[2][SPLIT][32 * VS / 4];
   const int u = blockIdx.z, h = blockIdx.y;
   const int qlo = q_off[u], nq = q_off[u + 1] - qlo;
   const int klo = k_off[u], nk = k_off[u + 1] - klo;
   if ((int)blockIdx.x * kAttnMfmaQ >= nq) return;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int grp = threadIdx.x >> 8;                // key group of this wave (SPLIT = 2: even / odd key blocks)
+  const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int q0 = blockIdx.x * kAttnMfmaQ + 32 * w;  // this wave's queries (waves beyond the utterance's end compute on its last query and store nothing)
   const int ql = min(q0 + l31, nq - 1);
   float qf[KC / 2];
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
   if constexpr (KCP > KC) {  // zero pad columns of both V stages (the staging below writes the real columns only)
     for (int i = tid; i < 2 * 32 * (KCP - KC) / 4; i += 256) {
       const int b = i / (32 * (KCP - KC) / 4), j = i % (32 * (KCP - KC) / 4), r = j / ((KCP - KC) / 4), g = j % ((KCP - KC) / 4);
-      Vs[b][r * (VS / 4) + G + g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      Vs[b][grp][r * (VS / 4) + G + g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   const int centre = band_centre ? band_centre[qlo + ql] : 0;
@@ -212,20 +217,23 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
     for (int e = 0; e < NE; ++e) {
       const int idx = tid + 256 * e, r = idx / G, g = idx % G;
       if (32 * G % 256 != 0 && idx >= 32 * G) continue;  // (heads whose 32 x KC block is not a multiple of 256 float4s)
-      float2* kd = reinterpret_cast<float2*>(&Ks[buf][r * KS + 4 * g]);  // (rows are 8-byte aligned: KS is even)
+      float2* kd = reinterpret_cast<float2*>(&Ks[buf][grp][r * KS + 4 * g]);  // (rows are 8-byte aligned: KS is even)
       kd[0] = make_float2(kreg[e].x, kreg[e].y);
       kd[1] = make_float2(kreg[e].z, kreg[e].w);
-      Vs[buf][r * (VS / 4) + g] = vreg[e];
+      Vs[buf][grp][r * (VS / 4) + g] = vreg[e];
     }
   };
-  gfetch(0);
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int buf = kb & 1;
+  // iteration it: group grp works on key block kb = SPLIT it + grp (a group past the last block stages zeros and skips the arithmetic)
+  const int nit = (nkb + SPLIT - 1) / SPLIT;
+  gfetch(min(grp, nkb - 1));
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1, kb = SPLIT * it + grp;
     lstore(buf);
-    if (kb + 1 < nkb) gfetch(kb + 1);
+    if (it + 1 < nit) gfetch(min(kb + SPLIT, nkb - 1));
     __syncthreads();
-    const float* kl = Ks[buf] + l31 * KS + lh;
-    const float* vl = reinterpret_cast<const float*>(Vs[buf]) + l31;
+    if (kb >= nkb) continue;
+    const float* kl = Ks[buf][grp] + l31 * KS + lh;
+    const float* vl = reinterpret_cast<const float*>(Vs[buf][grp]) + l31;
     // ---- S^T = K Q^T
     f32x16 sacc;
 #pragma unroll
@@ -267,6 +275,30 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const float* __rest
         const int key = 8 * (i >> 2) + 4 * lh + (i & 3);
         o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[key * VS + 32 * t], sacc[i], o[t], 0, 0, 0);
       }
+  }
+  if constexpr (SPLIT == 2) {
+    // merge the two key groups: group 1 parks (o, m, l) in the stage memory, group 0 combines (softmax over the union of the keys)
+    __syncthreads();  // every wave is done with the stages
+    float* xch = reinterpret_cast<float*>(Vs) + (size_t)w * (NT * 16 + 2) * 64 + lane;  // [wave][NT * 16 + 2][lane]
+    static_assert(sizeof(Vs) >= 4 * (NT * 16 + 2) * 64 * sizeof(float), "exchange area");
+    if (grp == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xch[(t * 16 + i) * 64] = o[t][i];
+      xch[(NT * 16) * 64] = m;
+      xch[(NT * 16 + 1) * 64] = lsum;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m2 = xch[(NT * 16) * 64], l2 = xch[(NT * 16 + 1) * 64];
+    const float mnew = fmaxf(m, m2);
+    const float s1 = expf(m - mnew), s2 = expf(m2 - mnew);  // (group 1 without a key block: m2 = -inf, s2 = 0, its o and l are zeros)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] = o[t][i] * s1 + xch[(t * 16 + i) * 64] * s2;
+    lsum = lsum * s1 + l2 * s2;
   }
   if (q0 + l31 < nq) {
     const float inv = 1.0f / lsum;

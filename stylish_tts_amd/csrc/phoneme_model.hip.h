@@ -285,10 +285,18 @@ inline int run_attention(hipStream_t st, const Seg& sq, const Seg& sk, const flo
   // batch, so that an utterance's result is the same alone and packed with others; other head sizes: one wave per 4 queries
   static const int mfma_min = getenv("STTS_ATTN_MFMA_MIN") ? atoi(getenv("STTS_ATTN_MFMA_MIN")) : 0;  // (experiments: shortest sequence for the matrix-core kernel)
   const bool aligned = ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && qcol0 % 4 == 0 && kcol0 % 4 == 0 && vcol0 % 4 == 0;
-  STTS_CHECK(force_kernel != 2 || (attn_mfma_kc(kc) && aligned), "attention: the matrix-core kernel needs heads of 16 / 32 / 40 / 64 / 96 / 128 / 160 channels and 16-byte aligned rows");
-  if (force_kernel == 2 || (force_kernel == 0 && attn_mfma_kc(kc) && aligned && sq.max_len() >= mfma_min && sk.max_len() >= mfma_min)) {
+  STTS_CHECK((force_kernel != 2 && force_kernel != 3) || (attn_mfma_kc(kc) && aligned), "attention: the matrix-core kernel needs heads of 16 / 32 / 40 / 64 / 96 / 128 / 160 channels and 16-byte aligned rows");
+  if (force_kernel == 2 || force_kernel == 3 || (force_kernel == 0 && attn_mfma_kc(kc) && aligned && sq.max_len() >= mfma_min && sk.max_len() >= mfma_min)) {
     const dim3 grid(ceil_div(sq.max_len(), kAttnMfmaQ), heads, sq.n_utt);
     const float scale = 1.0f / sqrtf((float)kc);
+    // long sequences with heads of 64 (the flow-matching decoder): the keys split over two wave groups per query tile (the result depends on the split,
+    // at fp32 rounding level: chosen by the LONGEST key sequence of the call, so an utterance alone and in a batch of shorter ones agree)
+    static const int split_min = getenv("STTS_ATTN_SPLIT_MIN") ? atoi(getenv("STTS_ATTN_SPLIT_MIN")) : 128;
+    if (kc == 64 && force_kernel != 3 && sk.max_len() >= split_min) {
+      hipLaunchKernelGGL((attention_mfma_kernel<64, 2>), grid, dim3(512), 0, st, Q, ldq, qcol0, K, ldk, kcol0, V, ldv, vcol0, O, ldo, sq.dev, sk.dev, band_centre, window, scale);
+      STTS_HIP(hipGetLastError());
+      return 0;
+    }
 #define STTS_ATTN(KCV) hipLaunchKernelGGL(attention_mfma_kernel<KCV>, grid, dim3(256), 0, st, Q, ldq, qcol0, K, ldk, kcol0, V, ldv, vcol0, O, ldo, sq.dev, sk.dev, band_centre, window, scale)
     if (kc == 16) STTS_ATTN(16);
     else if (kc == 32) STTS_ATTN(32);

@@ -72,7 +72,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,q_lens,k_lens,heads", CASES)
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])  # 1: one wave per four queries; 2: matrix cores (keys split over two wave groups from 128 keys on); 3: matrix cores, never split
 def test_attention_kernels_vs_float64(hip, name, q_lens, k_lens, heads, kernel):
     kc = 64
     k_lens = k_lens or q_lens
