@@ -43,6 +43,11 @@ int stts_ctx_create(const stts_model_dims* dims, int device, stts_ctx** out) {
 void stts_ctx_destroy(stts_ctx* c) {
   if (!c) return;
   for (void* p : c->allocs) (void)hipFree(p);
+  for (auto& kv : c->side_lanes) {
+    if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+    if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+    if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+  }
   delete c;
 }
 

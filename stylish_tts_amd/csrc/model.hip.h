@@ -134,6 +134,13 @@ struct stts_ctx {
   std::vector<int> alloc_tag;  // STTS_W_* component a device allocation belongs to (0: context lifetime); same length as allocs
   int cur_tag = 0;             // tag of the allocations made right now (set by the finalize sections)
   int* d_err = nullptr;
+  // side streams of stts_frame_path (fp32, large batches): one per caller stream (several host threads may run the path on their own streams)
+  struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+  };
+  std::map<hipStream_t, SideLane> side_lanes;
+  std::mutex side_mu;
   int ready = 0;  // STTS_W_* components finalized
   int prec = 0;   // contraction operand precision (stts::PREC_*), fixed before the first finalize
   int kc_align = 32;  // input channels of a packed conv are padded to this (64 while the frame path is packed for a 16-bit mode: conv_gemm16_kernel's K tile)
@@ -1716,6 +1723,9 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   const size_t side_bytes = (size_t)R * (sizeof(double) + kHop * sizeof(float)) + 4096 + 8 * s.n_utt;
   const size_t side_off = top.used;
   char* side_ws = top.get<char>(side_bytes);
+  // (side stream, below: the prior convs then need scratch of their own - the decoder uses the stage region at the same time)
+  const bool side_cfg = c->prec == PREC_F32 && R > 4096 && c->wino_prior[0].ready;
+  float* side_scratch = side_cfg ? top.get<float>(wino_scratch_floats(s, c->wino_prior[0])) : nullptr;
   STTS_CHECK(top.ok, "frame_path: workspace too small");
   const size_t mark = top.used;
   auto stage = [&]() {
@@ -1726,6 +1736,38 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   // < 1 % at B = 8 (7.51 vs 7.57 ms/step): the decoder GEMMs already fill the chip, so the stages stay on one stream.
   // 16-bit operand modes, large batches: the spectra are only read by the prior convs, so the STFT writes them as 16-bit rows
   const int h16 = vocoder_rows16(c, R) ? c->prec : 0;
+  // fp32, large batches: the source -> STFT -> prior-conv chain (independent of decoder and flow until the vocoder) runs on a SIDE STREAM of the caller's
+  // stream (fork / join events; the prior convs' scratch is its own region, carved above): it fills the chip while the decoder runs its small
+  // bandwidth-bound kernels.  Same kernels, same results; same-box A/B at cfg2: 4.41 -> 4.36 ms per step (round 1, when the step took 7.5 ms and the
+  // prior convs were direct contractions, the same experiment gained < 1 %).  Not while the per-launch profiler is on (its events belong to one stream),
+  // not in the 16-bit modes (the persistent contraction kernel of the decoder and that of the prior convs would fight for the same CUs).
+  const bool side_off_env = getenv("STTS_NO_SIDE_STREAM") != nullptr;  // experiments / tests (read per call)
+  if (side_scratch && !dry_run().on && !gemm_profiler().on && !side_off_env) {
+    stts_ctx::SideLane lane;
+    {
+      std::lock_guard<std::mutex> lock(c->side_mu);
+      stts_ctx::SideLane& l = c->side_lanes[st];
+      if (!l.stream) {
+        STTS_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        STTS_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+        STTS_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+      }
+      lane = l;
+    }
+    STTS_HIP(hipEventRecord(lane.fork, st));
+    STTS_HIP(hipStreamWaitEvent(lane.stream, lane.fork, 0));
+    { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, lane.stream, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a, h16)); }
+    WinoScratch wino;
+    wino.p = side_scratch;
+    STTS_TRY(prior_conv(c, lane.stream, s, 0, hs, ldh, headA, &wino, nullptr, h16 != 0));
+    STTS_TRY(prior_conv(c, lane.stream, s, 1, hp, ldh, headP, &wino, nullptr, h16 != 0));
+    STTS_HIP(hipEventRecord(lane.join, lane.stream));
+    { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
+    { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a, mel16, ldm16)); }
+    STTS_HIP(hipStreamWaitEvent(st, lane.join, 0));
+    { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, dh, style, headA, headP, audio, nullptr, nullptr, 0, a, mel16)); }
+    return 0;
+  }
   { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, st, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a, h16)); }
   {
     Arena a = stage();

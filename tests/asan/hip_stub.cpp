@@ -70,6 +70,16 @@ hipError_t hipEventDestroy(hipEvent_t e) {
   free(e);
   return hipSuccess;
 }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = (hipStream_t)malloc(8);
+  return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+  free(s);
+  return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) {

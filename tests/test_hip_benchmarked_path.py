@@ -205,3 +205,33 @@ def test_bench_inputs_match_the_oracle(hip, weights):
         err = np.abs(audio.cpu().numpy()[75 * u * T4 : 75 * (u + 1) * T4] - ref[0, 0]).max()
         print(f"\n[bench cfg2 inputs] utterance {u}: decoder rel err {ex:.2e}, waveform max-abs err vs oracle {err:.2e}")
         assert err < 1e-3, err
+
+
+def test_side_stream_equals_single_stream(hip, monkeypatch):
+    """fp32, large batches: stts_frame_path runs the source -> STFT -> prior-conv chain on a side stream of the caller's stream (fork / join events).
+    Same kernels, same inputs: the waveform must be BIT-IDENTICAL to the single-stream order (STTS_NO_SIDE_STREAM=1), on the default stream, on a
+    stream of the caller's, and when called again right away (the next call's fork must wait for this call's join)."""
+    from stylish_tts_amd import synth
+
+    B, T4 = 8, 960
+    s = segs([T4] * B)
+    asr = dev(np.concatenate([synth.normal(f"side.asr{b}", (T4, 128)) for b in range(B)]))
+    pitch = dev(np.concatenate([synth.pitch_curve(f"side.pitch{b}", 1, T4)[0] for b in range(B)]))
+    energy = dev(np.concatenate([(synth.uniform(f"side.energy{b}", (T4,)) * 2 + 2).astype(np.float32) for b in range(B)]))
+    style = dev((synth.normal("side.style", (B, 64)) * 0.7).astype(np.float32))
+    nz = synth.path_noise("side", B, T4)
+    pn = dev(nz["prior_noise"].transpose(0, 2, 1).reshape(B * T4, 128))
+    sn, ph0 = dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1))
+    run = lambda: hip.frame_path(s, asr, pitch, energy, style, pn, sn, ph0, batch_scope=True).clone()  # noqa: E731
+    monkeypatch.setenv("STTS_NO_SIDE_STREAM", "1")
+    ref = run()
+    monkeypatch.delenv("STTS_NO_SIDE_STREAM")
+    a, b = run(), run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c = run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ref).all())
+    assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
