@@ -1724,7 +1724,8 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   const size_t side_off = top.used;
   char* side_ws = top.get<char>(side_bytes);
   // (side stream, below: the prior convs then need scratch of their own - the decoder uses the stage region at the same time)
-  const bool side_cfg = c->prec == PREC_F32 && R > 4096 && c->wino_prior[0].ready;
+  static const long side_min_rows = getenv("STTS_SIDE_MIN_ROWS") ? atol(getenv("STTS_SIDE_MIN_ROWS")) : 3000;
+  const bool side_cfg = c->prec == PREC_F32 && R > side_min_rows && c->wino_prior[0].ready;
   float* side_scratch = side_cfg ? top.get<float>(wino_scratch_floats(s, c->wino_prior[0])) : nullptr;
   STTS_CHECK(top.ok, "frame_path: workspace too small");
   const size_t mark = top.used;
@@ -1738,8 +1739,9 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   const int h16 = vocoder_rows16(c, R) ? c->prec : 0;
   // fp32, large batches: the source -> STFT -> prior-conv chain (independent of decoder and flow until the vocoder) runs on a SIDE STREAM of the caller's
   // stream (fork / join events; the prior convs' scratch is its own region, carved above): it fills the chip while the decoder runs its small
-  // bandwidth-bound kernels.  Same kernels, same results; same-box A/B at cfg2: 4.41 -> 4.36 ms per step (round 1, when the step took 7.5 ms and the
-  // prior convs were direct contractions, the same experiment gained < 1 %).  Not while the per-launch profiler is on (its events belong to one stream),
+  // bandwidth-bound kernels.  Same kernels, same results; same-box A/B (3-s utterances): B = 8: 4.43 -> 4.38 ms per step (+1.2 %), B = 4: 2.91 -> 2.86
+  // (+1.6 %), B = 2: +0.8 %, B = 1: 1.76 -> 1.78 (the two cross-queue waits cost more than the overlap gains: off below 3 000 rows; STTS_SIDE_MIN_ROWS).
+  // (Round 1, when the step took 7.5 ms and the prior convs were direct contractions, the same experiment gained < 1 %.)  Not while the per-launch profiler is on (its events belong to one stream),
   // not in the 16-bit modes (the persistent contraction kernel of the decoder and that of the prior convs would fight for the same CUs).
   const bool side_off_env = getenv("STTS_NO_SIDE_STREAM") != nullptr;  // experiments / tests (read per call)
   if (side_scratch && !dry_run().on && !gemm_profiler().on && !side_off_env) {
