@@ -207,21 +207,25 @@ def test_bench_inputs_match_the_oracle(hip, weights):
         assert err < 1e-3, err
 
 
-def test_side_stream_equals_single_stream(hip, monkeypatch):
-    """fp32, large batches: stts_frame_path runs the source -> STFT -> prior-conv chain on a side stream of the caller's stream (fork / join events).
-    Same kernels, same inputs: the waveform must be BIT-IDENTICAL to the single-stream order (STTS_NO_SIDE_STREAM=1), on the default stream, on a
-    stream of the caller's, and when called again right away (the next call's fork must wait for this call's join)."""
+@pytest.mark.parametrize("lens", [[960] * 8, [100, 960, 37, 800, 1200, 20, 640]], ids=["cfg2", "ragged"])
+def test_side_stream_equals_single_stream(hip, monkeypatch, lens):
+    """fp32, batches of 3 000 rows and more: stts_frame_path runs the source -> STFT -> prior-conv chain on a side stream of the caller's stream (fork /
+    join events).  Same kernels, same inputs: the waveform must be BIT-IDENTICAL to the single-stream order (STTS_NO_SIDE_STREAM=1), on the default
+    stream, on a stream of the caller's, and when called again right away (the next call's fork must wait for this call's join); equal-length and
+    ragged batches."""
     from stylish_tts_amd import synth
 
-    B, T4 = 8, 960
-    s = segs([T4] * B)
-    asr = dev(np.concatenate([synth.normal(f"side.asr{b}", (T4, 128)) for b in range(B)]))
-    pitch = dev(np.concatenate([synth.pitch_curve(f"side.pitch{b}", 1, T4)[0] for b in range(B)]))
-    energy = dev(np.concatenate([(synth.uniform(f"side.energy{b}", (T4,)) * 2 + 2).astype(np.float32) for b in range(B)]))
+    B = len(lens)
+    assert sum(lens) > 3000  # model.hip.h frame_path: side_min_rows
+    s = segs(lens)
+    asr = dev(np.concatenate([synth.normal(f"side.asr{b}", (t, 128)) for b, t in enumerate(lens)]))
+    pitch = dev(np.concatenate([synth.pitch_curve(f"side.pitch{b}", 1, t)[0] for b, t in enumerate(lens)]))
+    energy = dev(np.concatenate([(synth.uniform(f"side.energy{b}", (t,)) * 2 + 2).astype(np.float32) for b, t in enumerate(lens)]))
     style = dev((synth.normal("side.style", (B, 64)) * 0.7).astype(np.float32))
-    nz = synth.path_noise("side", B, T4)
-    pn = dev(nz["prior_noise"].transpose(0, 2, 1).reshape(B * T4, 128))
-    sn, ph0 = dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1))
+    nzs = [synth.path_noise(f"side{b}", 1, t) for b, t in enumerate(lens)]
+    pn = dev(np.concatenate([n["prior_noise"][0].T for n in nzs]))
+    sn = dev(np.concatenate([n["src_noise"].reshape(-1) for n in nzs]))
+    ph0 = dev(nzs[0]["init_phase"].reshape(-1))
     run = lambda: hip.frame_path(s, asr, pitch, energy, style, pn, sn, ph0, batch_scope=True).clone()  # noqa: E731
     monkeypatch.setenv("STTS_NO_SIDE_STREAM", "1")
     ref = run()
