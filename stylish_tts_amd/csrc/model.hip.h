@@ -398,9 +398,8 @@ inline int pack_adain_block(stts_ctx* c, const std::string& p, int cin, int cout
   }
   STTS_TRY(pack_plain(c, p + ".conv2", true, 0, cout, &o->conv2));
   o->w2 = WinoConv();
-  if (find(c, p + ".conv1x1.parametrizations.weight.original0") || find(c, p + ".conv1x1.weight")) {
-    STTS_TRY(pack_plain(c, p + ".conv1x1", false, 0, cin, &o->sc));
-  } else if (c->prec == PREC_F32) {  // identity shortcut: conv2 is a plain conv + residual, so it has a Winograd form too
+  if (find(c, p + ".conv1x1.parametrizations.weight.original0") || find(c, p + ".conv1x1.weight")) STTS_TRY(pack_plain(c, p + ".conv1x1", false, 0, cin, &o->sc));
+  if (c->prec == PREC_F32) {  // conv2 is a plain conv + residual (the block's input, or its learned 1x1 shortcut computed first): it has a Winograd form too
     HostTensor w2;
     STTS_TRY(get_weight(c, p + ".conv2", &w2));
     if (w2.shape[2] == 3) STTS_TRY(pack_winograd(c, w2, find(c, p + ".conv2.bias"), 0, cout, cout, &o->w2));
@@ -988,7 +987,9 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     a.ld_xaff = B.kcin;
   }
   const bool wino1 = !fold && wino && *wino && B.w1.ready && force_tile == 0;
-  const bool wino2 = !fold && wino && *wino && B.w2.ready && !B.sc.W && force_tile == 0;
+  // (learned shortcut: conv2 in Winograd form + the 1x1 shortcut as a contraction of its own, added as the Winograd conv's residual)
+  static const bool wino2_sc = getenv("STTS_NO_WINO_CONV2SC") == nullptr;
+  const bool wino2 = !fold && wino && *wino && B.w2.ready && (!B.sc.W || wino2_sc) && force_tile == 0;
   // 16-bit operand modes, large batches: the normalised activations are WRITTEN as 16-bit rows (act1 / act2 reinterpreted),
   // so the contractions stage half the bytes and convert nothing; a learned shortcut reads a rounded copy of x (xs16)
   const int h16 = (s.rows() >= rows16_threshold() && B.conv1.prec != PREC_F32 && force_tile == 0 && (!B.sc.W || xs16) && ldx % 8 == 0) ? B.conv1.prec : 0;
@@ -1056,7 +1057,17 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     b.ldy16 = ldy16;
   }
   if (wino2) {
-    STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, x, ldx, b.alpha, *wino, act2, B.cout));
+    const float* res = x;
+    int ld_res = ldx;
+    if (B.sc.W) {  // act1 is free again (conv1 has consumed it): the shortcut's output lives there
+      GemmArgs g = gemm_args(s);
+      set_seg(g, 0, x, ldx, 0, B.sc);
+      g.N = B.cout; g.bias = nullptr; g.Y = act1; g.ldy = B.cout;
+      STTS_TRY(launch_conv_gemm(st, g, EPI_STORE, B.sc.npad, s.n_utt, ml, 0));
+      res = act1;
+      ld_res = B.cout;
+    }
+    STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, res, ld_res, b.alpha, *wino, act2, B.cout));
   } else {
     if (fuse_stats && stats->out && gemm16_will_run(b, EPI_STORE, B.conv2.npad, s.n_utt)) {
       b.stat_part = stats->out; b.ld_stat = stats->out_ld; b.stat_nchunk = nchunk;
