@@ -932,6 +932,11 @@ inline int pending_finish(hipStream_t st, PendingReduce* p) {
   STTS_HIP(hipGetLastError());
   return 0;
 }
+// batches up to this many rows fold AdaIN into the consuming contraction's staging (run_adain_block); above it the decoder convs run in Winograd form
+inline long fold_rows() {
+  static const long v = getenv("STTS_FOLD_ROWS") ? atol(getenv("STTS_FOLD_ROWS")) : 2500;
+  return v;
+}
 struct AdainStats {
   float* in = nullptr;   // statistics of x for norm1 (layout of adain_partial_kernel, round_up(cin, 32) columns)
   bool in_ready = false;
@@ -961,8 +966,9 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   // it (conv_gemm_f32<..., XAFF>): the statistics pass stays, a 64-thread kernel turns them into per-(utterance, channel)
   // scale / shift tables (kept in act1 / act2), and the normalised tensor is never written: B = 1 frame path -4 %.
   // Large batches keep the separate apply pass: the affine in the K loop costs the 512-channel contractions ~14 % at
-  // B = 8 (142 vs 125 us), more than the 11 us pass it removes.
-  const bool fold = s.rows() <= 4096;
+  // B = 8 (142 vs 125 us), more than the 11 us pass it removes.  fp32: from 2 500 rows on both convs run in Winograd form instead (AdaIN rides in
+  // their input transforms): 3-s utterances, same box: B = 3: 2.78 -> 2.63 ms, B = 4: 2.88 -> 2.83; B = 2: 2.16 -> 2.26 and B = 1: 1.77 -> 1.92 (fold stays).
+  const bool fold = s.rows() <= (B.conv1.prec == PREC_F32 ? fold_rows() : 4096);  // (16-bit modes: measured at 4 096 only)
   STTS_CHECK(ldx >= B.kcin, "adain block: input leading dimension %d < padded channels %d", ldx, B.kcin);
   auto affine = [&](const float* X, int ld, int C, int ld_aff, int gcol0, float* aff, PendingReduce* pend = nullptr) {
     const int nchunk = ceil_div(ml, kStatChunk), ldp = round_up(C, 32);
@@ -1108,7 +1114,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
-  if (R > 4096 && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
+  if (R > fold_rows() && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
   // 16-bit modes, large batches: rounded copies of the blocks' inputs for the learned shortcuts, ping-pong like xa / xb: a block's
   // conv2 epilogue writes the hidden columns of the next block's copy, the constant columns (asr_res, F0, N) are rounded once
   const bool x16 = R >= rows16_threshold() && c->prec != PREC_F32 && d.dec_hidden % 8 == 0;

@@ -490,7 +490,7 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
   float* act2 = ws.get<float>(Rf * C);
   float* ss = ws.get<float>(adain_part_floats(sf, C));
   WinoScratch wino;  // large batches: Winograd convs
-  if (Rf > 4096 && P.f0[0].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(sf, P.f0[0].w1));
+  if (Rf > fold_rows() && P.f0[0].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(sf, P.f0[0].w1));
   STTS_CHECK(ws.ok, "pitch_energy_forward: workspace too small");
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sp.max_len(), 256), sp.n_utt), dim3(256), 0, st, sp.dev, sp.n_utt, row_utt_p);
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sf.max_len(), 256), sf.n_utt), dim3(256), 0, st, sf.dev, sf.n_utt, row_utt_f);

@@ -65,13 +65,15 @@ def adopt_reference_branches(phase_dev, spec_dev, g, B, T4):
     return dev(out), adopted, bad
 
 
-def test_cfg2_batch8_reproduces_the_reference_waveform(hip):
+@pytest.mark.parametrize("B", [8, 3], ids=["B8", "B3"])
+def test_cfg2_batch8_reproduces_the_reference_waveform(hip, B):
+    """B = 8: the bench configuration.  B = 3 (2 880 rows): the smallest batches that take the large-batch branches (fp32: from 2 500 rows), without the side stream."""
     from stylish_tts_amd import synth
 
     g = load_golden("frame_path_3s")
-    B, T4 = 8, 960
+    T4 = 960
     s = segs([T4] * B)
-    assert s.rows > 4096  # the large-batch branches (model.hip.h: run_adain_block `fold`, decoder Winograd conv1)
+    assert s.rows > 2500  # model.hip.h fold_rows(): the large-batch branches (run_adain_block `fold` off, decoder convs in Winograd form)
     tile_rows = lambda a: dev(np.tile(a, (B, 1)))  # noqa: E731
     asr = tile_rows(synth.normal("g3.asr", (1, 128, T4))[0].T)
     pitch = dev(np.tile(synth.pitch_curve("g3.pitch", 1, T4)[0], B))
