@@ -1761,7 +1761,10 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
   // (Round 1, when the step took 7.5 ms and the prior convs were direct contractions, the same experiment gained < 1 %.)  Not while the per-launch profiler is on (its events belong to one stream),
   // not in the 16-bit modes (the persistent contraction kernel of the decoder and that of the prior convs would fight for the same CUs).
   const bool side_off_env = getenv("STTS_NO_SIDE_STREAM") != nullptr;  // experiments / tests (read per call)
-  if (side_scratch && !dry_run().on && !gemm_profiler().on && !side_off_env) {
+  // (not while the caller's stream is being captured into a graph: the lane's stream and events are created on first use, which a capture may not allow)
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (side_scratch && !side_off_env) (void)hipStreamIsCapturing(st, &capturing);
+  if (side_scratch && !dry_run().on && !gemm_profiler().on && !side_off_env && capturing == hipStreamCaptureStatusNone) {
     stts_ctx::SideLane lane;
     {
       std::lock_guard<std::mutex> lock(c->side_mu);

@@ -80,6 +80,10 @@ hipError_t hipStreamDestroy(hipStream_t s) {
   return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* status) {
+  *status = hipStreamCaptureStatusNone;
+  return hipSuccess;
+}
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) {

@@ -241,3 +241,4 @@ def test_side_stream_equals_single_stream(hip, monkeypatch, lens):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(ref).all())
     assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
+
