@@ -1778,15 +1778,28 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
     }
     STTS_HIP(hipEventRecord(lane.fork, st));
     STTS_HIP(hipStreamWaitEvent(lane.stream, lane.fork, 0));
-    { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, lane.stream, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a, h16)); }
-    WinoScratch wino;
-    wino.p = side_scratch;
-    STTS_TRY(prior_conv(c, lane.stream, s, 0, hs, ldh, headA, &wino, nullptr, h16 != 0));
-    STTS_TRY(prior_conv(c, lane.stream, s, 1, hp, ldh, headP, &wino, nullptr, h16 != 0));
+    // Whatever fails from here on, the caller's stream joins the side stream before this call returns: work that is still running there reads and
+    // writes the caller's workspace, which the caller is free to reuse (in stream order) as soon as it has the status.
+    auto forked = [&]() -> int {
+      { Arena a(side_ws, side_bytes, side_off); STTS_TRY(harmonic_stft(c, lane.stream, s, pitch, src_noise, init_phase, batch_scope, nullptr, hs, hp, ldh, a, h16)); }
+      WinoScratch wino;
+      wino.p = side_scratch;
+      STTS_TRY(prior_conv(c, lane.stream, s, 0, hs, ldh, headA, &wino, nullptr, h16 != 0));
+      STTS_TRY(prior_conv(c, lane.stream, s, 1, hp, ldh, headP, &wino, nullptr, h16 != 0));
+      return 0;
+    };
+    int rc = forked();
     STTS_HIP(hipEventRecord(lane.join, lane.stream));
-    { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
-    { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a, mel16, ldm16)); }
+    if (rc == 0) {
+      auto main_part = [&]() -> int {
+        { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
+        { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a, mel16, ldm16)); }
+        return 0;
+      };
+      rc = main_part();
+    }
     STTS_HIP(hipStreamWaitEvent(st, lane.join, 0));
+    if (rc) return rc;
     { Arena a = stage(); STTS_TRY(vocoder_body(c, st, s, mel, dh, style, headA, headP, audio, nullptr, nullptr, 0, a, mel16)); }
     return 0;
   }
