@@ -93,13 +93,15 @@ __device__ __forceinline__ float4 load4_16(const unsigned short* X, long idx, in
   const f16x4_t v = *reinterpret_cast<const f16x4_t*>(X + idx);
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
+// chunk_rows (<= kStatChunk): rows per chunk - 128, or 24 where the statistics have to line up with those a Winograd output transform leaves
+// (winograd_output_kernel<N, true>: four groups of six rows per block)
 __global__ void __launch_bounds__(256) adain_partial_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off,
-                                                            float* __restrict__ part, int ldp, int nchunk) {
+                                                            float* __restrict__ part, int ldp, int nchunk, int chunk_rows) {
   __shared__ float red[8][33];
   const int u = blockIdx.z, ch = blockIdx.y;
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), cl = threadIdx.x & 31;
   const int rl = threadIdx.x >> 5;
-  const int lo = seg_off[u] + ch * kStatChunk, hi = min(seg_off[u + 1], lo + kStatChunk);
+  const int lo = seg_off[u] + ch * chunk_rows, hi = min(seg_off[u + 1], lo + chunk_rows);
   if (lo >= hi) return;
   const bool ok = c < C;
   float v[kStatChunk / 8];
@@ -225,18 +227,19 @@ __global__ void __launch_bounds__(256) adain_partial_reduce_kernel(float* __rest
 // merge of the chunk statistics of channel c of utterance u (len rows) with the style affine:
 //   (1 + gamma) * (x - mean) * rstd + beta = x * scale + shift
 __device__ __forceinline__ void adain_scale_shift(const float* __restrict__ part, int ldp, int nchunk, int u, int c, int len,
-                                                  const float* __restrict__ gb, int ld_gb, int gcol0, int C, float eps, float* scale, float* shift) {
+                                                  const float* __restrict__ gb, int ld_gb, int gcol0, int C, float eps, float* scale, float* shift,
+                                                  int chunk_rows = kStatChunk) {
   const float n = (float)len;
-  const int nch = (len + kStatChunk - 1) / kStatChunk;
+  const int nch = (len + chunk_rows - 1) / chunk_rows;
   float mean = 0.f;
   for (int ch = 0; ch < nch; ++ch) {
-    const float nc = (float)min(kStatChunk, len - ch * kStatChunk);
+    const float nc = (float)min(chunk_rows, len - ch * chunk_rows);
     mean += nc * part[((long)(u * nchunk + ch) * 2) * ldp + c];
   }
   mean /= n;
   float m2 = 0.f;
   for (int ch = 0; ch < nch; ++ch) {
-    const float nc = (float)min(kStatChunk, len - ch * kStatChunk);
+    const float nc = (float)min(chunk_rows, len - ch * chunk_rows);
     const float* p = part + ((long)(u * nchunk + ch) * 2) * ldp;
     const float d = p[c] - mean;
     m2 += p[ldp + c] + nc * d * d;
@@ -252,11 +255,63 @@ __device__ __forceinline__ void adain_scale_shift(const float* __restrict__ part
 // grid (ceil(ld_aff / 64), n_utt), block 64.
 __global__ void __launch_bounds__(64) adain_affine_kernel(const float* __restrict__ part, int ldp, int nchunk, const int* __restrict__ seg_off,
                                                           const float* __restrict__ gb, int ld_gb, int gcol0, int C, float eps,
-                                                          float* __restrict__ aff, int ld_aff) {
+                                                          float* __restrict__ aff, int ld_aff, int chunk_rows) {
   const int u = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
   if (c >= ld_aff) return;
   float sc = 0.f, sh = 0.f;
-  if (c < C) adain_scale_shift(part, ldp, nchunk, u, c, seg_off[u + 1] - seg_off[u], gb, ld_gb, gcol0, C, eps, &sc, &sh);
+  if (c < C) adain_scale_shift(part, ldp, nchunk, u, c, seg_off[u + 1] - seg_off[u], gb, ld_gb, gcol0, C, eps, &sc, &sh, chunk_rows);
+  aff[((long)u * 2) * ld_aff + c] = sc;
+  aff[((long)u * 2 + 1) * ld_aff + c] = sh;
+}
+
+// The same table with the merge spread over 16 chunk lanes per channel (block 256 = 16 channels x 16 lanes, grid (ceil(ld_aff / 16), n_utt)): a lane
+// owns chunks lane, lane + 16, ...; its loads of a phase are independent, so a phase costs a few L2 round trips instead of one per chunk (the
+// single-thread merge walks 2 x nchunk dependent-latency loads: 7.5 us at 8 chunks, and the Winograd-path statistics have 40 chunks of 24 rows at 3 s).
+// Chan's update in a fixed order (lane partial sums in lane order): deterministic.
+__global__ void __launch_bounds__(256) adain_affine_lanes_kernel(const float* __restrict__ part, int ldp, int nchunk, const int* __restrict__ seg_off,
+                                                                 const float* __restrict__ gb, int ld_gb, int gcol0, int C, float eps,
+                                                                 float* __restrict__ aff, int ld_aff, int chunk_rows) {
+  __shared__ float red[16][17];
+  const int u = blockIdx.y, cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int len = seg_off[u + 1] - seg_off[u];
+  const int nch = (len + chunk_rows - 1) / chunk_rows;
+  const bool ok = c < C;
+  const float* p0 = part + ((long)u * nchunk * 2) * ldp + (ok ? c : 0);
+  float acc = 0.f;
+#pragma unroll 4
+  for (int ch = lane; ch < nch; ch += 16) {
+    const float nc = (float)min(chunk_rows, len - ch * chunk_rows);
+    acc += nc * p0[(long)ch * 2 * ldp];
+  }
+  red[lane][cl] = acc;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mean += red[i][cl];
+  mean /= (float)len;
+  __syncthreads();
+  acc = 0.f;
+#pragma unroll 4
+  for (int ch = lane; ch < nch; ch += 16) {
+    const float nc = (float)min(chunk_rows, len - ch * chunk_rows);
+    const float* p = p0 + (long)ch * 2 * ldp;
+    const float d = p[0] - mean;
+    acc += p[ldp] + nc * d * d;
+  }
+  red[lane][cl] = acc;
+  __syncthreads();
+  if (lane != 0 || c >= ld_aff) return;
+  float sc = 0.f, sh = 0.f;
+  if (ok && len > 0) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2 += red[i][cl];
+    const float rstd = rsqrtf(m2 / (float)len + eps);
+    const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
+    sc = rstd * (1.0f + g);
+    sh = be - mean * sc;
+  }
   aff[((long)u * 2) * ld_aff + c] = sc;
   aff[((long)u * 2 + 1) * ld_aff + c] = sh;
 }

@@ -804,7 +804,7 @@ inline size_t wino_scratch_floats(const Seg& s, const WinoConv& wc) {
 }
 template <int N>
 inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
-                          float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0) {
+                          float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0, float* stat = nullptr, int ld_stat = 0) {
   const int n = wc.mats.n, kc = wc.planes.kc, ldm = round_up(wc.planes.N, 32), ml = s.max_len();
   long pr = 0;  // rows of a component plane: the groups of 4 output rows of all utterances, packed
   for (int u = 0; u < s.n_utt; ++u) pr += ceil_div(s.host[u + 1] - s.host[u], kWinoM);
@@ -847,8 +847,13 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
       return rc;
     }
   }
-  hipLaunchKernelGGL((winograd_output_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(ceil_div(wc.planes.N, 4), 64), s.n_utt), dim3(64, 4), 0, st, Mp, ldm, goff,
-                     s.dev, to, wc.planes.bias, act, R, ldr, alpha, Y, ldy, wc.planes.N);
+  // stat: the output transform also leaves the AdaIN statistics of Y per chunk of kWinoStatChunk rows (wino_stat_chunks(s) chunks per utterance)
+  if (stat)
+    hipLaunchKernelGGL((winograd_output_kernel<N, true>), dim3(ceil_div(groups, 4), ceil_div(ceil_div(wc.planes.N, 4), 64), s.n_utt), dim3(64, 4), 0, st, Mp, ldm, goff,
+                       s.dev, to, wc.planes.bias, act, R, ldr, alpha, Y, ldy, wc.planes.N, stat, ld_stat, ceil_div(groups, 4));
+  else
+    hipLaunchKernelGGL((winograd_output_kernel<N, false>), dim3(ceil_div(groups, 4), ceil_div(ceil_div(wc.planes.N, 4), 64), s.n_utt), dim3(64, 4), 0, st, Mp, ldm, goff,
+                       s.dev, to, wc.planes.bias, act, R, ldr, alpha, Y, ldy, wc.planes.N, nullptr, 0, 0);
   if (timed) {
     prof.on = true;
     (void)hipEventRecord(prof.next(), st);
@@ -858,12 +863,14 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   STTS_HIP(hipGetLastError());
   return 0;
 }
+inline int wino_stat_chunks(const Seg& s) { return ceil_div(ceil_div(s.max_len(), kWinoM), 4); }
 inline int run_winograd(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
-                        float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0) {
+                        float alpha, WinoScratch& scratch, const float* aff = nullptr, int ld_aff = 0, float* stat = nullptr, int ld_stat = 0) {
   STTS_CHECK(wc.ready && (wc.mats.n == 8 || wc.mats.n == 12), "winograd conv not packed");
   STTS_CHECK(ldx % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "winograd conv: leading dimensions must be multiples of 4");
-  return wc.mats.n == 8 ? run_winograd_n<8>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff)
-                        : run_winograd_n<12>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff);
+  STTS_CHECK(!stat || (ld_stat % 4 == 0 && ld_stat >= round_up(wc.planes.N, 4)), "winograd conv: statistics rows of %d floats do not cover %d channels", ld_stat, wc.planes.N);
+  return wc.mats.n == 8 ? run_winograd_n<8>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff, stat, ld_stat)
+                        : run_winograd_n<12>(st, s, X, ldx, wc, Y, ldy, act, R, ldr, alpha, scratch, aff, ld_aff, stat, ld_stat);
 }
 
 inline int run_style(hipStream_t st, const StyleTable& t, const float* style, int n_utt, float* out) {
@@ -892,14 +899,14 @@ inline long rows16_threshold() {
 
 // AdaIN + activation: Y[:, :ldy] = act((1+gamma) * InstanceNorm(X[:, :C]) + beta), zeros in the pad columns.
 // part: scratch of adain_part_floats(s, C) floats.
-inline size_t adain_part_floats(const Seg& s, int C) { return (size_t)s.n_utt * ceil_div(s.max_len(), kStatChunk) * 2 * round_up(C, 32); }
+inline size_t adain_part_floats(const Seg& s, int C, int chunk_rows = kStatChunk) { return (size_t)s.n_utt * ceil_div(s.max_len(), chunk_rows) * 2 * round_up(C, 32); }
 // out16: PREC_BF16 / PREC_F16 = Y is a 16-bit row buffer (ldy in elements), the input of a contraction in that operand mode
 inline int run_adain(hipStream_t st, const Seg& s, const float* X, int ldx, int C, float* Y, int ldy, const float* style_out, int ld_style,
                      int gcol0, int act, const float* alpha, float* part, int out16 = 0, bool have_stats = false) {
   // have_stats: `part` already holds the chunk statistics of X (written by the producing contraction's epilogue, GemmArgs::stat_part)
   const int nchunk = ceil_div(s.max_len(), kStatChunk), ldp = round_up(C, 32);
   if (!have_stats)
-    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk);
+    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ldx, C, s.dev, part, ldp, nchunk, kStatChunk);
   const int rb = (long)ceil_div(ldy, 64) * ceil_div(s.rows(), 64) >= 4096 ? 256 : 64;  // rows per block
   STTS_LAUNCH_PROF("adain_apply_kernel", (size_t)s.rows() * (C * 4 + ldy * (out16 ? 2 : 4)), adain_apply_kernel, dim3(ceil_div(ldy, 64), ceil_div(s.max_len(), rb), s.n_utt), dim3(256), st, X, ldx, Y, ldy, C, s.dev,
                      part, ldp, nchunk, style_out, ld_style, gcol0, 1e-5f, act, alpha, out16, rb);
@@ -944,6 +951,7 @@ struct AdainStats {
   float* out = nullptr;  // where conv2 writes the statistics of y
   int out_ld = 0;
   bool out_ready = false;
+  int chunk_rows = kStatChunk;  // kWinoStatChunk: fp32 Winograd branch, the statistics come out of the convs' output transforms (winograd_output_kernel<N, true>)
 };
 // AdaptiveDecoderBlock (models/ada_norm.py:166-182).  x [rows, ldx] (cols >= cin may hold anything when
 // kcin == round_up(cin) because the packed weights are zero there, but AdaIN writes zeros anyway).
@@ -970,6 +978,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   // their input transforms): 3-s utterances, same box: B = 3: 2.78 -> 2.63 ms, B = 4: 2.88 -> 2.83; B = 2: 2.16 -> 2.26 and B = 1: 1.77 -> 1.92 (fold stays).
   const bool fold = s.rows() <= (B.conv1.prec == PREC_F32 ? fold_rows() : 4096);  // (16-bit modes: measured at 4 096 only)
   STTS_CHECK(ldx >= B.kcin, "adain block: input leading dimension %d < padded channels %d", ldx, B.kcin);
+  static const bool affine_lanes = getenv("STTS_AFFINE_SERIAL") == nullptr;  // experiments: the one-thread-per-channel merge (adain_affine_kernel)
   auto affine = [&](const float* X, int ld, int C, int ld_aff, int gcol0, float* aff, PendingReduce* pend = nullptr) {
     const int nchunk = ceil_div(ml, kStatChunk), ldp = round_up(C, 32);
     if (pend && pend->src.partial) {  // the producer's reduce pass rides in the statistics launch (X's first columns are written here)
@@ -977,9 +986,13 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
                        const_cast<float*>(X), ld, C, s.dev, ss, ldp, nchunk, pend->src);
       pend->src = SplitSrc{};
     } else
-    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ld, C, s.dev, ss, ldp, nchunk);
+    STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)s.rows() * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, s.n_utt), dim3(256), st, X, ld, C, s.dev, ss, ldp, nchunk, kStatChunk);
+    if (affine_lanes)
+      STTS_LAUNCH_PROF("adain_affine_lanes_kernel", (size_t)s.n_utt * nchunk * 2 * ldp * 4, adain_affine_lanes_kernel, dim3(ceil_div(ld_aff, 16), s.n_utt), dim3(256), st, ss, ldp, nchunk, s.dev, style_out, ld_style,
+                       gcol0, C, 1e-5f, aff, ld_aff, kStatChunk);
+    else
     STTS_LAUNCH_PROF("adain_affine_kernel", (size_t)s.n_utt * nchunk * 2 * ldp * 4, adain_affine_kernel, dim3(ceil_div(ld_aff, 64), s.n_utt), dim3(64), st, ss, ldp, nchunk, s.dev, style_out, ld_style, gcol0, C,
-                       1e-5f, aff, ld_aff);
+                       1e-5f, aff, ld_aff, kStatChunk);
   };
   // norm1 -> LeakyReLU -> conv1
   GemmArgs a = gemm_args(s);
@@ -996,6 +1009,14 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   // (learned shortcut: conv2 in Winograd form + the 1x1 shortcut as a contraction of its own, added as the Winograd conv's residual)
   static const bool wino2_sc = getenv("STTS_NO_WINO_CONV2SC") == nullptr;
   const bool wino2 = !fold && wino && *wino && B.w2.ready && (!B.sc.W || wino2_sc) && force_tile == 0;
+  // fp32 Winograd branch: every normalised tensor is the output of a Winograd conv (conv1 -> norm2, conv2 -> the next block's norm1), whose output
+  // transform leaves the chunk statistics behind: the norms keep only their 64-thread affine launch (no adain_partial_kernel pass)
+  const bool wstats = stats && stats->chunk_rows == kWinoStatChunk && wino1 && wino2;
+  auto affine_from = [&](const float* part, int C, int ld_aff, int gcol0, float* aff) {
+    const int wch = wino_stat_chunks(s), ldp = round_up(C, 32);
+    STTS_LAUNCH_PROF("adain_affine_lanes_kernel", (size_t)s.n_utt * wch * 2 * ldp * 4, adain_affine_lanes_kernel, dim3(ceil_div(ld_aff, 16), s.n_utt), dim3(256), st, part, ldp, wch, s.dev, style_out, ld_style,
+                     gcol0, C, 1e-5f, aff, ld_aff, kWinoStatChunk);
+  };
   // 16-bit operand modes, large batches: the normalised activations are WRITTEN as 16-bit rows (act1 / act2 reinterpreted),
   // so the contractions stage half the bytes and convert nothing; a learned shortcut reads a rounded copy of x (xs16)
   const int h16 = (s.rows() >= rows16_threshold() && B.conv1.prec != PREC_F32 && force_tile == 0 && (!B.sc.W || xs16) && ldx % 8 == 0) ? B.conv1.prec : 0;
@@ -1015,8 +1036,9 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   if (wino1) {
     // large batches: conv1 (k = 3) in Winograd F(6,3) form, 8 instead of 18 multiplies per 6 outputs (winograd.hip.h); AdaIN + LeakyReLU ride
     // in its input transform (an elementwise, bandwidth-bound kernel: there the affine is free, unlike in the K loop)
-    affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1);
-    STTS_TRY(run_winograd(st, s, x, ldx, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino, act1, B.kcin));
+    if (wstats && stats->in_ready) affine_from(stats->in, B.cin, B.kcin, B.n1.col0, act1);
+    else affine(x, ldx, B.cin, B.kcin, B.n1.col0, act1);
+    STTS_TRY(run_winograd(st, s, x, ldx, B.w1, hbuf, B.cout, ACT_NONE, nullptr, 0, 1.0f, *wino, act1, B.kcin, wstats ? stats->mid : nullptr, round_up(B.cout, 32)));
   } else {
     if (fuse_stats && gemm16_will_run(a, EPI_STORE, B.conv1.npad, s.n_utt)) {
       a.stat_part = stats->mid; a.ld_stat = round_up(B.cout, 32); a.stat_nchunk = nchunk;
@@ -1035,7 +1057,8 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
     b.xaff = act2;
     b.ld_xaff = B.cout;
   } else if (wino2) {
-    affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2);
+    if (wstats) affine_from(stats->mid, B.cout, B.cout, B.n2.col0, act2);
+    else affine(hbuf, B.cout, B.cout, B.cout, B.n2.col0, act2);
   } else {
     STTS_TRY(run_adain(st, s, hbuf, B.cout, B.cout, act2, B.cout, style_out, ld_style, B.n2.col0, ACT_LRELU, nullptr, mid_ready ? stats->mid : ss, h16, mid_ready));
     set_seg(b, 0, act2, B.cout, 0, B.conv2);
@@ -1073,7 +1096,9 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
       res = act1;
       ld_res = B.cout;
     }
-    STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, res, ld_res, b.alpha, *wino, act2, B.cout));
+    const bool leave = wstats && stats->out;  // the statistics of y for the next block's norm1 (its hidden columns)
+    STTS_TRY(run_winograd(st, s, hbuf, B.cout, B.w2, y, ldy, ACT_NONE, res, ld_res, b.alpha, *wino, act2, B.cout, leave ? stats->out : nullptr, leave ? stats->out_ld : 0));
+    if (leave) stats->out_ready = true;
   } else {
     if (fuse_stats && stats->out && gemm16_will_run(b, EPI_STORE, B.conv2.npad, s.n_utt)) {
       b.stat_part = stats->out; b.ld_stat = stats->out_ld; b.stat_nchunk = nchunk;
@@ -1109,8 +1134,8 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* hbuf = ws.get<float>(R * d.dec_hidden);
   float* act2 = ws.get<float>(R * d.dec_hidden);
   float* ss = ws.get<float>(adain_part_floats(s, ldwide));
-  float* ss_in = ws.get<float>(adain_part_floats(s, ldwide));   // 16-bit modes: statistics from the contractions' epilogues (AdainStats)
-  float* ss_mid = ws.get<float>(adain_part_floats(s, ldwide));
+  float* ss_in = ws.get<float>(adain_part_floats(s, ldwide, kWinoStatChunk));   // statistics from the producers' epilogues (AdainStats): 16-bit contractions, or
+  float* ss_mid = ws.get<float>(adain_part_floats(s, ldwide, kWinoStatChunk));  // the fp32 Winograd output transforms (chunks of 24 rows: the larger footprint)
   float* sty = ws.get<float>((size_t)s.n_utt * c->dec_style.ld());
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
@@ -1146,23 +1171,27 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   // 16-bit modes, large batches: the statistics of a block's input come out of the previous block's conv2 epilogue (its 512 hidden columns) and,
   // for the constant columns [asr_res | F0 | N] that every decode block sees, from ONE statistics pass here
   static const bool no_stat_fuse = getenv("STTS_NO_STAT_FUSE") != nullptr;  // experiments: every norm runs its own statistics pass
+  static const bool no_wino_stats = getenv("STTS_NO_WINO_STATS") != nullptr;  // experiments: the fp32 Winograd branch runs a statistics pass per norm
+  const bool wstat_mode = c->prec == PREC_F32 && wino && !no_wino_stats;
+  const bool use_stats = (x16 && !no_stat_fuse) || wstat_mode;
   AdainStats stats;
+  if (wstat_mode) stats.chunk_rows = kWinoStatChunk;
   stats.mid = ss_mid;
   stats.out = ss_in;
   stats.out_ld = round_up(ccat, 32);
   // small batches: a block's conv2 leaves its split-K reduce pass to the next block's first statistics launch (PendingReduce)
   PendingReduce pend;
-  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat, (x16 && !no_stat_fuse) ? &stats : nullptr,
+  STTS_TRY(run_adain_block(st, s, c->dec[0], sty, lds, enc_in, ldenc, xa, ldcat, act1, hbuf, act2, ss, 0, &wino, xs16b, false, xs16a, ldcat, use_stats ? &stats : nullptr,
                            nullptr, &pend));
   if (x16) {
     cast_tail(xa, xs16a);
     cast_tail(xb, xs16b);
   }
   if (stats.out_ready) {
-    const int nchunk = ceil_div(s.max_len(), kStatChunk), cc0 = d.dec_hidden, ncst = ccat - cc0;
+    const int nchunk = ceil_div(s.max_len(), stats.chunk_rows), cc0 = d.dec_hidden, ncst = ccat - cc0;
     STTS_CHECK(cc0 % 32 == 0, "decoder_forward: hidden_dim must be a multiple of 32");
     STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)R * ncst * 4, adain_partial_kernel, dim3(ceil_div(ncst, 32), nchunk, s.n_utt), dim3(256), st, xa + cc0, ldcat, ncst, s.dev,
-                     ss_in + cc0, stats.out_ld, nchunk);
+                     ss_in + cc0, stats.out_ld, nchunk, stats.chunk_rows);
   }
   float* cur = xa;
   float* nxt = xb;
@@ -1175,7 +1204,7 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     stats.in_ready = stats.out_ready;  // (the previous block's conv2 ran on conv_gemm16_kernel and left the statistics of its output)
     stats.out = i == 4 ? nullptr : ss_in;
     STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat,
-                             (x16 && !no_stat_fuse) ? &stats : nullptr, &pend, &pend));
+                             use_stats ? &stats : nullptr, &pend, &pend));
     std::swap(cur, nxt);
     std::swap(cur16, nxt16);
   }

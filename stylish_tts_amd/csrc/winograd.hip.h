@@ -170,38 +170,79 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 }
 
 // Y[row][n] = (act(sum_j At[i][j] M_j[group][n] + bias[n]) [+ R[row][n]]) * alpha for the rows of each group inside its utterance
-template <int N>
+// STATS: the block also leaves the AdaIN statistics of its 4 groups = kWinoStatChunk rows of Y (chunk blockIdx.x of the utterance) behind, in
+// adain_partial_kernel's layout with chunk_rows = kWinoStatChunk: stat[((u * stat_nchunk + chunk) * 2 + {0: mean, 1: M2}) * ld_stat + n] - the
+// consuming AdaIN (models/ada_norm.py:129-139) then needs no pass over Y of its own.  Two passes over the registers (mean, then centred squares).
+constexpr int kWinoStatChunk = 4 * kWinoM;
+template <int N, bool STATS>
 __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ Mp, int ldm, const int* __restrict__ goff, const int* __restrict__ seg_off,
                                                               const WinoOut t, const float* __restrict__ bias, int act, const float* __restrict__ R,
-                                                              int ldr, float alpha, float* __restrict__ Y, int ldy, int Nout) {
+                                                              int ldr, float alpha, float* __restrict__ Y, int ldy, int Nout,
+                                                              float* __restrict__ stat, int ld_stat, int stat_nchunk) {
   const int u = blockIdx.z;
   const int lo = seg_off[u], len = seg_off[u + 1] - lo;
   const int groups = (len + kWinoM - 1) / kWinoM;
   const int g = blockIdx.x * 4 + threadIdx.y;
   const int n4 = (blockIdx.y * 64 + threadIdx.x) * 4;
-  if (g >= groups || n4 >= Nout) return;
-  const long prow = goff[u] + g, plane_rows = goff[gridDim.z];
-  f32x4 m[N];
+  const bool live = g < groups && n4 < Nout;
+  if (!STATS && !live) return;
+  if (STATS && (int)blockIdx.x * kWinoStatChunk >= len) return;  // (uniform: no row of this chunk exists)
+  f32x4 o[kWinoM];
 #pragma unroll
-  for (int j = 0; j < N; ++j) m[j] = *reinterpret_cast<const f32x4*>(Mp + ((long)j * plane_rows + prow) * ldm + n4);
-  f32x4 b = {0.f, 0.f, 0.f, 0.f};
-  if (bias) b = *reinterpret_cast<const f32x4*>(bias + n4);
+  for (int i = 0; i < kWinoM; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const long prow = goff[u] + g, plane_rows = goff[gridDim.z];
+    f32x4 m[N];
 #pragma unroll
-  for (int i = 0; i < kWinoM; ++i) {
-    const int row = g * kWinoM + i;
-    if (row < len) {
-      f32x4 v = b;
+    for (int j = 0; j < N; ++j) m[j] = *reinterpret_cast<const f32x4*>(Mp + ((long)j * plane_rows + prow) * ldm + n4);
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b = *reinterpret_cast<const f32x4*>(bias + n4);
 #pragma unroll
-      for (int j = 0; j < N; ++j) v += t.At[i][j] * m[j];
-      float* y = Y + (long)(lo + row) * ldy + n4;
+    for (int i = 0; i < kWinoM; ++i) {
+      const int row = g * kWinoM + i;
+      if (row < len) {
+        f32x4 v = b;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (n4 + c < Nout) {
-          float e = act_apply(v[c], act);
-          if (R) e += R[(long)(lo + row) * ldr + n4 + c];
-          y[c] = e * alpha;
+        for (int j = 0; j < N; ++j) v += t.At[i][j] * m[j];
+        float* y = Y + (long)(lo + row) * ldy + n4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (n4 + c < Nout) {
+            float e = act_apply(v[c], act);
+            if (R) e += R[(long)(lo + row) * ldr + n4 + c];
+            e *= alpha;
+            y[c] = e;
+            o[i][c] = e;
+          }
         }
       }
+    }
+  }
+  if (STATS) {
+    __shared__ f32x4 red[4][64];
+    const int nrows = min(kWinoStatChunk, len - (int)blockIdx.x * kWinoStatChunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kWinoM; ++i) acc += o[i];  // rows beyond the utterance hold zeros
+    red[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    const f32x4 mean = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * (1.0f / (float)nrows);
+    __syncthreads();
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kWinoM; ++i) {
+      if (g * kWinoM + i < len) {
+        const f32x4 dv = o[i] - mean;
+        acc += dv * dv;
+      }
+    }
+    red[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && n4 < Nout) {
+      const f32x4 m2 = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      float* p = stat + ((long)(u * stat_nchunk + blockIdx.x) * 2) * ld_stat + n4;
+      *reinterpret_cast<f32x4*>(p) = mean;
+      *reinterpret_cast<f32x4*>(p + ld_stat) = m2;
     }
   }
 }
