@@ -328,18 +328,47 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
   const int lo = seg_off[u], hi = seg_off[u + 1];
   const int r0 = lo + blockIdx.y * rb;
   if (r0 >= hi) return;
-  // the block's 64 channels: one thread per channel merges the chunk statistics, result shared through LDS
-  __shared__ float s_sc[64], s_sh[64], s_al[64];
-  if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    float scv = 0.f, shv = 0.f, alv = 1.f;
-    if (c < C) {
-      adain_scale_shift(part, ldp, nchunk, u, c, hi - lo, gb, ld_gb, gcol0, C, eps, &scv, &shv);
-      if (alpha) alv = alpha[c];
+  // the block's 64 channels: four chunk lanes per channel merge the chunk statistics (Chan's update, lane partial sums in lane order: deterministic;
+  // a lane's loads of a phase are independent - one thread per channel walked 2 x nchunk dependent loads before the block's first row moved:
+  // 25 chunks at 10 s), result shared through LDS
+  __shared__ float s_sc[64], s_sh[64], s_al[64], s_red[4][64];
+  {
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int len = hi - lo;
+    const int nch = (len + kStatChunk - 1) / kStatChunk;
+    const bool ok = c < C;
+    const float* p0 = part + ((long)u * nchunk * 2) * ldp + (ok ? c : 0);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int ch = lane; ch < nch; ch += 4) acc += (float)min(kStatChunk, len - ch * kStatChunk) * p0[(long)ch * 2 * ldp];
+    s_red[lane][cl] = acc;
+    __syncthreads();
+    const float mean = (s_red[0][cl] + s_red[1][cl] + s_red[2][cl] + s_red[3][cl]) / (float)len;
+    __syncthreads();
+    acc = 0.f;
+#pragma unroll 4
+    for (int ch = lane; ch < nch; ch += 4) {
+      const float* p = p0 + (long)ch * 2 * ldp;
+      const float d = p[0] - mean;
+      acc += p[ldp] + (float)min(kStatChunk, len - ch * kStatChunk) * d * d;
     }
-    s_sc[threadIdx.x] = scv;
-    s_sh[threadIdx.x] = shv;
-    s_al[threadIdx.x] = alv;
+    s_red[lane][cl] = acc;
+    __syncthreads();
+    if (lane == 0) {
+      float scv = 0.f, shv = 0.f, alv = 1.f;
+      if (ok) {
+        const float m2 = s_red[0][cl] + s_red[1][cl] + s_red[2][cl] + s_red[3][cl];
+        const float rstd = rsqrtf(m2 / (float)len + eps);
+        const float g = gb[(long)u * ld_gb + gcol0 + c], be = gb[(long)u * ld_gb + gcol0 + C + c];
+        scv = rstd * (1.0f + g);
+        shv = be - mean * scv;
+        if (alpha) alv = alpha[c];
+      }
+      s_sc[cl] = scv;
+      s_sh[cl] = shv;
+      s_al[cl] = alv;
+    }
   }
   __syncthreads();
   const int cl = (threadIdx.x & 15) * 4;
