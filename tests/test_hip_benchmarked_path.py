@@ -242,3 +242,32 @@ def test_side_stream_equals_single_stream(hip, monkeypatch, lens):
     assert bool(torch.isfinite(ref).all())
     assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
 
+
+
+def test_ragged_decoder_on_the_winograd_statistics_path_vs_the_oracle(hip, weights):
+    """fp32, more than 2 500 rows: every AdaIN of the decoder takes its statistics from the preceding Winograd conv's output transform (chunks of 24 rows,
+    winograd_output_kernel<N, true>) and the lane-parallel merge (adain_affine_lanes_kernel).  Ragged lengths that are multiples of neither 6 (a Winograd
+    group) nor 24 (a statistics chunk), one shorter than a chunk: Decoder.forward (models/decoder.py:47-60, models/ada_norm.py:129-182) per utterance vs the oracle."""
+    from oracle import stylish_oracle as O
+    from stylish_tts_amd import synth
+
+    lens = [997, 13, 1201, 613, 25]
+    assert sum(lens) > 2500  # model.hip.h fold_rows(): the Winograd branch
+    B = len(lens)
+    s = segs(lens)
+    asr_h = [synth.normal(f"wst.asr{b}", (t, 128)) for b, t in enumerate(lens)]
+    pitch_h = [synth.pitch_curve(f"wst.pitch{b}", 1, t)[0] for b, t in enumerate(lens)]
+    energy_h = [(synth.uniform(f"wst.energy{b}", (t,)) * 2 + 2).astype(np.float32) for b, t in enumerate(lens)]
+    style_h = (synth.normal("wst.style", (B, 64)) * 0.7).astype(np.float32)
+    x = hip.decoder(s, dev(np.concatenate(asr_h)), dev(np.concatenate(pitch_h)), dev(np.concatenate(energy_h)), dev(style_h))
+    hip.check_status()
+    x = x.cpu().numpy()
+    assert np.isfinite(x).all()
+    w = weights["speech_predictor"]
+    lo = 0
+    for u, t in enumerate(lens):
+        xd = O.decoder_forward(asr_h[u].T[None].copy(), pitch_h[u][None], energy_h[u][None], style_h[u : u + 1], w)
+        err = np.abs(x[lo : lo + t, :512].T - xd[0]).max() / np.abs(xd).max()
+        print(f"\n[winograd statistics path] utterance {u} ({t} frames): decoder rel err {err:.2e}")
+        assert err < 2e-4, (u, t, err)
+        lo += t
