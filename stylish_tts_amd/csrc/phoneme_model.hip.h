@@ -491,6 +491,12 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
   float* ss = ws.get<float>(adain_part_floats(sf, C));
   WinoScratch wino;  // large batches: Winograd convs
   if (Rf > fold_rows() && P.f0[0].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(sf, P.f0[0].w1));
+  // ... whose output transforms leave the AdaIN statistics of what they write (decoder_forward's scheme: AdainStats with 24-row chunks)
+  static const bool no_wino_stats = getenv("STTS_NO_WINO_STATS") != nullptr;
+  const bool wstat_mode = wino && !no_wino_stats;
+  float* ss_in = wstat_mode ? ws.get<float>(adain_part_floats(sf, C, kWinoStatChunk)) : nullptr;
+  float* ss_mid = wstat_mode ? ws.get<float>(adain_part_floats(sf, C, kWinoStatChunk)) : nullptr;
+  float* ss_x = wstat_mode ? ws.get<float>(adain_part_floats(sf, C, kWinoStatChunk)) : nullptr;  // statistics of x: one pass for both branches' first norm
   STTS_CHECK(ws.ok, "pitch_energy_forward: workspace too small");
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sp.max_len(), 256), sp.n_utt), dim3(256), 0, st, sp.dev, sp.n_utt, row_utt_p);
   hipLaunchKernelGGL(row_utt_kernel, dim3(ceil_div(sf.max_len(), 256), sf.n_utt), dim3(256), 0, st, sf.dev, sf.n_utt, row_utt_f);
@@ -518,8 +524,21 @@ inline int pitch_energy_forward(stts_ctx* c, PhonemeModel& M, hipStream_t st, co
     const AdainBlockW* blocks = br == 0 ? P.f0 : P.n;
     const float* cur = x;
     float* bufs[2] = {t1, t2};
+    AdainStats stats;
+    stats.chunk_rows = kWinoStatChunk;
+    stats.mid = ss_mid;
+    const bool x_stats = wstat_mode && blocks[0].cin == C && C % 32 == 0;
+    if (x_stats && br == 0) {
+      const int nchunk = wino_stat_chunks(sf);
+      STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)Rf * C * 4, adain_partial_kernel, dim3(ceil_div(C, 32), nchunk, sf.n_utt), dim3(256), st, x, C, C, sf.dev, ss_x, C, nchunk, kWinoStatChunk);
+    }
     for (int i = 0; i < 3; ++i) {
-      STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss, 0, &wino));
+      // norm1 of blocks 1, 2: statistics left by the previous block's conv2; norm2: by this block's conv1 (both Winograd output transforms)
+      stats.in = i == 0 ? ss_x : ss_in;
+      stats.in_ready = i == 0 ? x_stats : (stats.out_ready && blocks[i].cin == blocks[i - 1].cout);
+      stats.out = (i < 2 && blocks[i].cout <= C) ? ss_in : nullptr;
+      stats.out_ld = round_up(blocks[i].cout, 32);
+      STTS_TRY(run_adain_block(st, sf, blocks[i], sty, lds, cur, C, bufs[i & 1], C, act1, hb, act2, ss, 0, &wino, nullptr, false, nullptr, 0, wstat_mode ? &stats : nullptr));
       cur = bufs[i & 1];
     }
     const ChanConvSet cs{cur, br == 0 ? P.f0_w : P.n_w, br == 0 ? P.f0_b : P.n_b, br == 0 ? f0 : nrg};
