@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 // Y[row][n] = (act(sum_j At[i][j] M_j[group][n] + bias[n]) [+ R[row][n]]) * alpha for the rows of each group inside its utterance
 // STATS: the block also leaves the AdaIN statistics of its 4 groups = kWinoStatChunk rows of Y (chunk blockIdx.x of the utterance) behind, in
 // adain_partial_kernel's layout with chunk_rows = kWinoStatChunk: stat[((u * stat_nchunk + chunk) * 2 + {0: mean, 1: M2}) * ld_stat + n] - the
-// consuming AdaIN (models/ada_norm.py:129-139) then needs no pass over Y of its own.  Two passes over the registers (mean, then centred squares).
+// consuming AdaIN (models/ada_norm.py:129-139) then needs no pass over Y of its own.
 constexpr int kWinoStatChunk = 4 * kWinoM;
 template <int N, bool STATS>
 __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ Mp, int ldm, const int* __restrict__ goff, const int* __restrict__ seg_off,
@@ -219,27 +219,39 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
     }
   }
   if (STATS) {
-    __shared__ f32x4 red[4][64];
-    const int nrows = min(kWinoStatChunk, len - (int)blockIdx.x * kWinoStatChunk);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // a wave = one group: every thread reduces its own (up to six) rows first - mean and centred squares of the group, no exchange - and the block's
+    // four groups are merged by Chan's update in group order through LDS: one barrier, nothing kept in registers across it
+    __shared__ f32x4 red[2][4][64];
+    const int gn = min(kWinoM, max(0, len - g * kWinoM));  // rows of this wave's group inside the utterance
+    f32x4 gmean = {0.f, 0.f, 0.f, 0.f}, gm2 = {0.f, 0.f, 0.f, 0.f};
+    if (gn > 0) {
 #pragma unroll
-    for (int i = 0; i < kWinoM; ++i) acc += o[i];  // rows beyond the utterance hold zeros
-    red[threadIdx.y][threadIdx.x] = acc;
-    __syncthreads();
-    const f32x4 mean = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * (1.0f / (float)nrows);
-    __syncthreads();
-    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < kWinoM; ++i) gmean += o[i];  // rows beyond the utterance hold zeros
+      gmean *= 1.0f / (float)gn;
 #pragma unroll
-    for (int i = 0; i < kWinoM; ++i) {
-      if (g * kWinoM + i < len) {
-        const f32x4 dv = o[i] - mean;
-        acc += dv * dv;
+      for (int i = 0; i < kWinoM; ++i) {
+        if (i < gn) {
+          const f32x4 dv = o[i] - gmean;
+          gm2 += dv * dv;
+        }
       }
     }
-    red[threadIdx.y][threadIdx.x] = acc;
+    red[0][threadIdx.y][threadIdx.x] = gmean;
+    red[1][threadIdx.y][threadIdx.x] = gm2;
     __syncthreads();
     if (threadIdx.y == 0 && n4 < Nout) {
-      const f32x4 m2 = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      const int base = (int)blockIdx.x * kWinoStatChunk;
+      const int nrows = min(kWinoStatChunk, len - base);
+      f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mean += (float)min(kWinoM, max(0, len - base - w * kWinoM)) * red[0][w][threadIdx.x];
+      mean *= 1.0f / (float)nrows;
+      f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const f32x4 dv = red[0][w][threadIdx.x] - mean;
+        m2 += red[1][w][threadIdx.x] + (float)min(kWinoM, max(0, len - base - w * kWinoM)) * dv * dv;
+      }
       float* p = stat + ((long)(u * stat_nchunk + blockIdx.x) * 2) * ld_stat + n4;
       *reinterpret_cast<f32x4*>(p) = mean;
       *reinterpret_cast<f32x4*>(p + ld_stat) = m2;
