@@ -1187,12 +1187,18 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     cast_tail(xa, xs16a);
     cast_tail(xb, xs16b);
   }
-  if (stats.out_ready) {
+  // (once, as soon as a block has left statistics of its output: whichever block that is, the constant columns must be there before the next norm1 merges them)
+  bool const_ready = false;
+  auto const_columns = [&]() -> int {
+    if (!stats.out_ready || const_ready) return 0;
     const int nchunk = ceil_div(s.max_len(), stats.chunk_rows), cc0 = d.dec_hidden, ncst = ccat - cc0;
     STTS_CHECK(cc0 % 32 == 0, "decoder_forward: hidden_dim must be a multiple of 32");
     STTS_LAUNCH_PROF("adain_partial_kernel", (size_t)R * ncst * 4, adain_partial_kernel, dim3(ceil_div(ncst, 32), nchunk, s.n_utt), dim3(256), st, xa + cc0, ldcat, ncst, s.dev,
                      ss_in + cc0, stats.out_ld, nchunk, stats.chunk_rows);
-  }
+    const_ready = true;
+    return 0;
+  };
+  STTS_TRY(const_columns());
   float* cur = xa;
   float* nxt = xb;
   unsigned short* cur16 = xs16a;
@@ -1200,8 +1206,9 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   for (int i = 1; i <= 4; ++i) {
     float* dst = i == 4 ? x_out : nxt;
     const int ldd = i == 4 ? ld_x : ldcat;
+    STTS_TRY(const_columns());
     stats.in = ss_in;
-    stats.in_ready = stats.out_ready;  // (the previous block's conv2 ran on conv_gemm16_kernel and left the statistics of its output)
+    stats.in_ready = stats.out_ready;  // (the previous block's conv2 - conv_gemm16_kernel's epilogue or the fp32 Winograd output transform - left the statistics of its output)
     stats.out = i == 4 ? nullptr : ss_in;
     STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat,
                              use_stats ? &stats : nullptr, &pend, &pend));
