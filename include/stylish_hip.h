@@ -73,8 +73,14 @@ int stts_finalize_weights(stts_ctx* ctx, int which);
  * that produces them (larger calls: contraction inputs are 16-bit rows in HBM; the same arithmetic) - and products accumulate
  * in fp32; norms, gates, style projections, FFTs and every non-contraction kernel stay fp32.
  * The PHONEME-RATE predictors (text encoders, style encoders, duration and pitch / energy predictors) always run in fp32:
- * durations are integers (bit-exact against the fp32 reference in every mode) and those stages are latency-bound. */
-enum { STTS_PREC_F32 = 0, STTS_PREC_BF16 = 1, STTS_PREC_F16 = 2 };
+ * durations are integers (bit-exact against the fp32 reference in every mode) and those stages are latency-bound.
+ * F32, how the fp32 products are formed (round 4): every fp32 operand is the EXACT sum of three bf16 numbers (8 + 8 + 8 significand
+ * bits), so x * w is nine bf16 x bf16 products, each exact in fp32; the frame-rate contractions run the six largest on the bf16
+ * matrix cores with fp32 accumulation (the three dropped terms are <= 2^-23 |x w|, 2^-27 |x w| rms, zero-mean: below the
+ * rounding of the fp32 accumulation that both forms share).  Nothing is rounded to 16 bits: results agree with the
+ * f32 matrix cores' to fp32 accumulation noise (tests/test_hip_split_fp32.py measures both against float64).
+ * F32_NATIVE keeps every fp32 contraction on v_mfma_f32_32x32x2_f32 (rounds 1-3; also process-wide with STTS_NO_X3=1). */
+enum { STTS_PREC_F32 = 0, STTS_PREC_BF16 = 1, STTS_PREC_F16 = 2, STTS_PREC_F32_NATIVE = 3 };
 int stts_set_precision(stts_ctx* ctx, int precision);
 /* Reads the device-side error word (sets last_error): 1 = a voiced frame exists but no f0 > 20 Hz (the reference raises there,
  * models/generator.py:285), 2 = a token id outside the embedding table, 4 = an utterance

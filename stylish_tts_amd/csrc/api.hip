@@ -54,9 +54,11 @@ void stts_ctx_destroy(stts_ctx* c) {
 int stts_set_precision(stts_ctx* c, int precision) {
   API_BEGIN
   STTS_CHECK(c, "bad argument");
-  STTS_CHECK(precision >= 0 && precision <= 2, "precision must be STTS_PREC_F32, _BF16 or _F16");
-  STTS_CHECK(c->ready == 0 || precision == c->prec, "precision must be chosen before weights are finalized");
-  c->prec = precision;
+  STTS_CHECK(precision >= 0 && precision <= 3, "precision must be STTS_PREC_F32, _BF16, _F16 or _F32_NATIVE");
+  const int prec = precision == STTS_PREC_F32_NATIVE ? (int)PREC_F32 : precision;
+  STTS_CHECK(c->ready == 0 || (prec == c->prec && (precision != STTS_PREC_F32_NATIVE) == c->allow_x3), "precision must be chosen before weights are finalized");
+  c->prec = prec;
+  c->allow_x3 = precision != STTS_PREC_F32_NATIVE;
   return 0;
   API_END
 }
@@ -97,9 +99,12 @@ int stts_finalize_weights(stts_ctx* c, int which) {
     if (!c->phoneme) c->phoneme = std::make_shared<PhonemeModel>();
     // the phoneme-rate predictors always run in fp32 (include/stylish_hip.h, stts_set_precision): durations are integers and must
     // equal the fp32 reference's bit for bit, and these stages are latency-bound (nothing to win from 16-bit operands)
+    // (and on the f32 matrix cores, not the split-fp32 form: latency-bound launches, and per-utterance GRN weights in the style encoder)
     const int saved_prec = c->prec;
     c->prec = PREC_F32;
+    c->pack_x3 = false;
     const int rc = finalize_phoneme(c, static_cast<PhonemeModel*>(c->phoneme.get()), ph);
+    c->pack_x3 = true;
     c->prec = saved_prec;
     STTS_TRY(rc);
     c->ready |= ph;
@@ -251,7 +256,9 @@ int stts_cfm_finalize(stts_ctx* c, const stts_cfm_dims* dims) {
   d.enc_blocks = dims->enc_blocks; d.dec_blocks = dims->dec_blocks; d.prev_depth = dims->prev_depth; d.post_depth = dims->post_depth; d.head_dim = dims->head_dim;
   auto m = std::make_shared<CfmModel>();
   c->cur_tag = STTS_W_CFM;
+  c->pack_x3 = false;  // latency-bound estimator: f32 matrix cores
   const int rc = finalize_cfm(c, d, m.get());
+  c->pack_x3 = true;
   c->cur_tag = 0;
   if (rc) return rc;
   c->cfm = m;

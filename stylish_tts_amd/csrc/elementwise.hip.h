@@ -712,6 +712,23 @@ __global__ void __launch_bounds__(256) scale_weight_kernel(const float* __restri
   }
 }
 
+// GRN as an input affine of pwconv2 (split-fp32 contractions): xaff[u][0][k] = gamma[k] * gx[u][k] / (mean_k gx[u] + 1e-6) + 1, xaff[u][1][k] = 0;
+// pad columns k >= C get scale 0 (the contraction's staging treats scale 0 as "pad: contributes nothing").  models/generator.py:488-499
+__global__ void __launch_bounds__(256) grn_xaff_kernel(const float* __restrict__ gx, int ld_gx, const float* __restrict__ gamma, float* __restrict__ xaff, int ld, int C) {
+  __shared__ float red[4];
+  const int u = blockIdx.x;
+  float part = 0.f;
+  for (int k = threadIdx.x; k < C; k += 256) part += gx[(long)u * ld_gx + k];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1] + red[2] + red[3]) / (float)C + 1e-6f);
+  for (int k = threadIdx.x; k < ld; k += 256) {
+    xaff[((long)u * 2) * ld + k] = k < C ? gamma[k] * gx[(long)u * ld_gx + k] * inv + 1.f : 0.f;
+    xaff[((long)u * 2 + 1) * ld + k] = 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Length regulator part 2 + decoder front end (models/speech_predictor.py:88-97, models/decoder.py:48-51):
 //   frame t4 of utterance u takes token tok[t4>>2]           (alignment.repeat_interleave(4) then enc @ alignment)

@@ -47,7 +47,8 @@ enum Epi {
 struct GemmSeg {
   const float* X;     // time-major activations
   const float* W;     // packed [Npad][ntaps][kc]
-  const unsigned short* W16;  // the same tensor rounded to bf16 / fp16 (16-bit operand modes)
+  const unsigned short* W16;  // the same tensor rounded to bf16 / fp16 (16-bit operand modes); PREC_X3: the three bf16 planes of the exact split
+  long w16_plane;     // PREC_X3: elements between two planes of W16 (0: this weight has no split form)
   long w_utt_stride;  // floats between per-utterance copies of W (0: shared)
   int ldx, xcol0, kc, ntaps, dil, pad;
   int kreal;  // un-padded input channels (host side: algorithmic FLOP accounting only)
@@ -79,6 +80,7 @@ struct GemmArgs {
   // input affine of segment 0 (AdaIN folded into the staging): x' = lrelu_0.2(x * xaff[u][0][c] + xaff[u][1][c]); EPI_STORE only
   const float* xaff;
   int ld_xaff;
+  float xaff_slope;       // negative-side slope of that activation (0.2: LeakyReLU; 1: a pure per-channel scale / shift, e.g. GRN folded into pwconv2's staging)
   long long* dbg;         // block-timeline records (only written when built with -DSTTS_GEMM_TRACE; tools/gemm_bench.py)
   const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
   int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
@@ -136,7 +138,17 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // staged into LDS, weights are stored pre-rounded ([cout][tap][cin] 16-bit), products accumulate in fp32 on
 // v_mfma_f32_32x32x16_{bf16,f16}.  A 32-channel K chunk is then 64 bytes per tile row (4 slots of 16 bytes, swizzled by
 // (row >> 2) & 3) and two MFMAs instead of sixteen.
-enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+//
+// PREC_X3 ("split fp32"): the operands ARE the fp32 values.  Every fp32 number is the exact sum of three bf16 numbers
+// (x = x0 + x1 + x2, 3 x 8 significand bits, each term the round-to-nearest bf16 of what the previous ones left), so
+// x * w = sum of nine bf16 x bf16 products, each exact in fp32.  The kernel runs the six largest of them
+// (x0 w0, x0 w1, x1 w0, x0 w2, x1 w1, x2 w0) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped terms are
+// at most 2^-23 |x w| (one fp32 ulp of the product), 2^-27 |x w| rms and zero-mean (tests/test_split_fp32_cpu.py) - a quarter of
+// the rms error of rounding the product to fp32 once, and far below the rounding of the fp32 accumulation that both forms share
+// (tests/test_hip_split_fp32.py measures both forms against float64).  Weights are split once at pack time (three planes in W16,
+// w16_plane apart), activations stay fp32 in HBM and are split when a tile is staged into LDS.  Six bf16 MFMAs do the work of
+// sixteen v_mfma_f32_32x32x2_f32 in 3/8 of the matrix-pipe cycles.
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_X3 = 3 };
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -159,9 +171,21 @@ __device__ __forceinline__ u32x2 pack4_16(const f32x4 v) {
   }
   return r;
 }
+// exact three-term bf16 split of four fp32 values: v = p0 + p1 + p2 (each u32x2 = four bf16 in channel order)
+__device__ __forceinline__ void split3_bf16(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  auto pk = [](float a, float b) { const f2 t = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2)); };  // v_cvt_pk_bf16_f32 (RNE)
+  auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+  auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+  p0.x = pk(v.x, v.y); p0.y = pk(v.z, v.w);
+  const float r0 = v.x - lo(p0.x), r1 = v.y - hi(p0.x), r2 = v.z - lo(p0.y), r3 = v.w - hi(p0.y);  // exact
+  p1.x = pk(r0, r1); p1.y = pk(r2, r3);
+  p2.x = pk(r0 - lo(p1.x), r1 - hi(p1.x)); p2.y = pk(r2 - lo(p1.y), r3 - hi(p1.y));                 // exact remainders, representable in bf16
+}
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma16(const f32x4 a, const f32x4 b, const f32x16 c) {
-  if constexpr (PREC == PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  if constexpr (PREC == PREC_BF16 || PREC == PREC_X3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
@@ -175,12 +199,15 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   static_assert(!X16 || (PREC != PREC_F32 && !XAFF && EPI == EPI_STORE), "16-bit activation rows: 16-bit operand modes, store epilogue");
   constexpr int NT = WARPS_M * WARPS_N * 64 * KSPLIT;
   constexpr bool B16 = PREC != PREC_F32;
+  constexpr bool X3 = PREC == PREC_X3;  // split fp32: three bf16 planes per operand, six MFMAs per (tile, 16 channels)
+  constexpr int NPL = X3 ? 3 : 1;
+  static_assert(!X3 || (!GLDS && !X16), "split fp32: activations are fp32 rows, split on the register staging path");
   static_assert(!(B16 && GLDS) || X16, "LDS-DMA staging of 16-bit operands needs 16-bit activation rows (nothing converts on the way)");
   static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
   constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
   constexpr int TR = WR / 32, TC = WC / 32;
   constexpr int XL = X16 ? (BN * 4 + NT - 1) / NT : BN * 8 / NT;  // 16-byte X loads per thread per tile (16-bit rows: 4 per 32 channels)
-  constexpr int WL = B16 ? (BM * 4 + NT - 1) / NT : BM * 8 / NT;  // 16-byte W loads per thread per tile
+  constexpr int WL = B16 ? (BM * 4 * NPL + NT - 1) / NT : BM * 8 / NT;  // 16-byte W loads per thread per tile
   static_assert(WR % 32 == 0 && WC % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert((X16 || (BN * 8) % NT == 0) && (B16 || (BM * 8) % NT == 0), "tile loads must divide over the block");
   static_assert(EPI == EPI_STORE || EPI == EPI_SPLIT_ACC || TC % 2 == 0, "paired epilogues need an even TC");
@@ -189,7 +216,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // (three for the 256-row tiles; EIGHT for the 128 x 128 tile of small batches, whose K iteration - four MFMAs per wave - is far
   //  shorter than a memory round trip: with tiles requested two iterations ahead that loop ran at one iteration per ~0.6 us)
   constexpr int NSTAGE = (B16 && GLDS) ? ((BM + BN) <= 256 ? 8 : 3) : 2;
-  __shared__ f32x4 lds[NSTAGE * (BN + BM) * ((B16 && KSPLIT == 1) ? 4 : 8)];
+  // 16-byte slots per tile row and stage: fp32 8 (32 channels); 16-bit 4 per plane; split fp32: planes [p][X rows | W rows][4]
+  constexpr int SLOTS = X3 ? 12 : ((B16 && KSPLIT == 1) ? 4 : 8);
+  constexpr int PLANE = (BN + BM) * 4;      // 16-bit layouts: f32x4 slots of one plane of one stage
+  constexpr int STG16 = PLANE * NPL;        // ... of one stage
+  __shared__ f32x4 lds[NSTAGE * (BN + BM) * SLOTS];
 
   // XCD-aware block -> tile map (guide T1; speed only, any placement is correct): workgroups are dealt round-robin
   // over the 8 XCDs, each with its own L2.  Re-number them so that one XCD works through a CONTIGUOUS range of
@@ -323,12 +354,16 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // Offsets are relative to the utterance / the weight tile, hence always < 2^31 bytes.
   unsigned woff[WL];
   const int len = hi - lo, rel0 = row0 - lo;
+  long g_wplane = X3 ? a.seg[0].w16_plane : 0;
   auto seg_offsets = [&]() {
     const int wrow = g_ntaps * g_kc;
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int idx = tid + i * NT;
-      if constexpr (B16) woff[i] = (unsigned)((min(idx >> 2, BM - 1) * wrow + (idx & 3) * 8) * 2);  // 8 x 16-bit per load
+      if constexpr (X3) {  // plane-major: load idx covers (plane, row, 8 channels); the plane offset rides in the 32-bit byte offset (host-checked)
+        const int pl = min(idx / (BM * 4), 2), rem = idx % (BM * 4);
+        woff[i] = (unsigned)(((long)pl * g_wplane + (rem >> 2) * wrow + (rem & 3) * 8) * 2);
+      } else if constexpr (B16) woff[i] = (unsigned)((min(idx >> 2, BM - 1) * wrow + (idx & 3) * 8) * 2);  // 8 x 16-bit per load
       else woff[i] = (unsigned)(((idx >> 3) * wrow + (idx & 7) * 4) * 4);
     }
   };
@@ -379,6 +414,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+        if constexpr (X3) g_wplane = n.w16_plane;
         seg_offsets();
       }
     }
@@ -392,7 +428,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       for (int q = 0; q < 4; ++q) {
         // scale 0 marks a pad column: its X value may be uninitialised memory (NaN * 0 would poison the tile)
         const float y = (rs.sc[q] == 0.0f ? 0.0f : v[q] * rs.sc[q]) + rs.sh[q];
-        t[q] = y >= 0.0f ? y : 0.2f * y;
+        t[q] = y >= 0.0f ? y : a.xaff_slope * y;
       }
       v = rs.aff ? t : v;
     }
@@ -400,13 +436,21 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   };
   auto lstore = [&](const RegSet& rs, int b) {
     if constexpr (B16) {
-      f32x4* Xs = lds + b * (BN + BM) * 4;  // 4 x 16-byte slots (64 bytes) per row
+      f32x4* Xs = lds + b * STG16;  // 4 x 16-byte slots (64 bytes) per row (split fp32: per plane)
       f32x4* Ws = Xs + BN * 4;
       u32x2* Xh = reinterpret_cast<u32x2*>(Xs);
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
         const int idx = tid + i * NT;
-        if constexpr (X16) {  // rows arrive rounded: 16 bytes = 8 channels go straight into their slot
+        if constexpr (X3) {  // four fp32 channels -> their place in each of the three bf16 planes
+          const int r = idx >> 3, sl = idx & 7;
+          u32x2 p0, p1, p2;
+          split3_bf16(xin(rs, i), p0, p1, p2);
+          const int o = (r * 4 + ((sl >> 1) ^ ((r >> 2) & 3))) * 2 + (sl & 1);
+          Xh[o] = p0;
+          Xh[o + PLANE * 2] = p1;
+          Xh[o + PLANE * 4] = p2;
+        } else if constexpr (X16) {  // rows arrive rounded: 16 bytes = 8 channels go straight into their slot
           const int r = idx >> 2, sl = idx & 3;
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
           if (BN * 4 % NT == 0 || idx < BN * 4) Xs[r * 4 + (sl ^ ((r >> 2) & 3))] = rs.ok[i] ? rs.x[i] : z;
@@ -418,8 +462,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
         const int idx = tid + i * NT;
+        if constexpr (X3) {
+          const int pl = idx / (BM * 4), rem = idx % (BM * 4), n = rem >> 2, c = rem & 3;
+          if (BM * 12 % NT == 0 || idx < BM * 12) Ws[pl * PLANE + n * 4 + (c ^ ((n >> 2) & 3))] = rs.w[i];
+        } else {
         const int n = idx >> 2, c = idx & 3;
         if (BM * 4 % NT == 0 || idx < BM * 4) Ws[n * 4 + (c ^ ((n >> 2) & 3))] = rs.w[i];
+        }
       }
     } else {
     f32x4* Xs = lds + b * (BN + BM) * 8;
@@ -457,6 +506,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+        if constexpr (X3) g_wplane = n.w16_plane;
         seg_offsets();
       }
     }
@@ -491,9 +541,39 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 
   // 16-bit operands: kk = 0, 1 are the two 16-channel halves of the chunk; lanes 0-31 / 32-63 supply k 0-7 / 8-15
   auto mma_step16 = [&](int b, int kk) {
-    const f32x4* Xs = lds + b * (BN + BM) * 4;
+    const f32x4* Xs = lds + b * STG16;
     const f32x4* Ws = Xs + BN * 4;
     const int slot = 2 * kk + lh;
+    if constexpr (X3) {
+      f32x4 xa[TR][3], wb[TC][3];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int r = wn * WR + i * 32 + l31;
+        const int o = r * 4 + (slot ^ ((r >> 2) & 3));
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xa[i][p] = Xs[o + p * PLANE];
+      }
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        const int c = wm * WC + j * 32 + l31;
+        const int o = c * 4 + (slot ^ ((c >> 2) & 3));
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wb[j][p] = Ws[o + p * PLANE];
+      }
+      // the six products with p + q <= 2, smallest first (the accumulator takes the 2^-16 terms before the 2^-8 and the leading ones)
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+          acc[i][j] = mfma16<PREC>(xa[i][2], wb[j][0], acc[i][j]);
+          acc[i][j] = mfma16<PREC>(xa[i][0], wb[j][2], acc[i][j]);
+          acc[i][j] = mfma16<PREC>(xa[i][1], wb[j][1], acc[i][j]);
+          acc[i][j] = mfma16<PREC>(xa[i][1], wb[j][0], acc[i][j]);
+          acc[i][j] = mfma16<PREC>(xa[i][0], wb[j][1], acc[i][j]);
+          acc[i][j] = mfma16<PREC>(xa[i][0], wb[j][0], acc[i][j]);
+        }
+      return;
+    }
     f32x4 xa[TR], wb[TC];
     const bool nord = ablate(32);  // timing-only ablation: operands are not read from LDS
 #pragma unroll
@@ -708,7 +788,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   if constexpr (KSPLIT == 2) {
     // sum the two K-groups: group 1 parks its accumulators in LDS (the staging buffers are free now), group 0 adds them
     // and runs the epilogue alone.
-    static_assert(WARPS_M * WARPS_N * TR * TC * 16 * 64 * 4 <= 2 * (BN + BM) * 8 * 16, "reduction buffer must fit in the staging LDS");
+    static_assert(WARPS_M * WARPS_N * TR * TC * 16 * 64 * 4 <= NSTAGE * (BN + BM) * SLOTS * 16, "reduction buffer must fit in the staging LDS");
     float* red = reinterpret_cast<float*>(lds);
     if (kg == 1) {
 #pragma unroll
@@ -883,7 +963,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 
 // Finishes a block-level split-K contraction: Y = (act(sum_ks partial[ks] + bias) [+ R]) * alpha, partials summed in a
 // fixed order (deterministic).  One thread per (row, 4 columns).
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int rows, int row_first, int ld_part, int N,
+static __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int rows, int row_first, int ld_part, int N,
                                                             const float* __restrict__ bias, int act, const float* __restrict__ R, int ldr,
                                                             int rcol0, float alpha, float* __restrict__ Y, int ldy, int ycol0) {
   const int n4 = (N + 3) / 4;
@@ -1029,6 +1109,14 @@ inline bool gemm16_will_run(const GemmArgs& a, int epi, int npad, int n_utt);  /
 template <int ABL>
 inline int launch_conv_gemm16(hipStream_t st, const GemmArgs& a, int npad, int n_utt);
 
+// The contraction kernels are instantiated in one translation unit per operand form (csrc/gemm_tu_*.hip define STTS_GEMM_TU_FORM and
+// include this header; __graft_entry__.compile builds them in parallel); every other unit sees these declarations only.
+void gemm_dispatch_f32(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1);
+void gemm_dispatch_bf16(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1);
+void gemm_dispatch_f16(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1);
+void gemm_dispatch_x3(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1);
+int launch_conv_gemm16_main(hipStream_t st, const GemmArgs& a, int npad, int n_utt);  // = launch_conv_gemm16<0> (gemm_tu_g16.hip)
+
 #ifndef STTS_GEMM_NO_LAUNCHER  // (probes that only need the types and conv_gemm16_kernel skip the ~50 instantiations below)
 template <int BM, int BN, int WM, int WN, int KS = 1, bool GL = false, int PR = PREC_F32>
 inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -1072,6 +1160,75 @@ inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int
   }
 }
 
+// split fp32 (PREC_X3): store and prior epilogues only; the flow's generic gate / couple / split-accumulate launches stay on the f32 matrix cores
+template <int BM, int BN, int WM, int WN, int KS = 1>
+inline void launch_cfg_x3(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
+  if (a.compact) grid = dim3(npad / BM, a.tiles_y, a.ksplit > 1 ? a.ksplit : 1);
+  if (epi == EPI_PRIOR) {
+    if constexpr (BM / WM >= 64) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, false, PREC_X3>), grid, block, st, e0, e1, a);
+  } else if (a.xaff) {
+    if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, true, false>), grid, block, st, e0, e1, a);
+    else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, true, true>), grid, block, st, e0, e1, a);
+  } else if (a.nseg == 1) {
+    STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, false, false>), grid, block, st, e0, e1, a);
+  } else {
+    STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3>), grid, block, st, e0, e1, a);
+  }
+}
+// tile -> instantiation, per operand form.  Defined (= every kernel instantiated) only in the translation unit of that form.
+template <int PR>
+inline void gemm_dispatch_tile(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1) {
+  switch (tile) {
+    case 2: launch_cfg<128, 64, 2, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 4: launch_cfg<128, 32, 4, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 32-row tile, 4 waves of one 32x32 tile each
+    case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
+    case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
+    case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
+    case 14:  // 256 cout x 256 rows, 8 waves of 64 x 128 (8 accumulator tiles): 16-bit operands at large batches, where the
+              // 128x128 loop is bound by L2 -> LDS staging (47 B/clk/CU needed); this tile needs 31
+      if constexpr (PR != PREC_F32) launch_cfg<256, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+      break;
+    case 15:
+      if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+      break;
+    case 16:  // tiles 14 / 15 with LDS-DMA staging (global_load_lds_dwordx4, three stages): 16-bit activation rows only
+      if constexpr (PR != PREC_F32) launch_cfg<256, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+      break;
+    case 17:
+      if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+      break;
+    case 18:  // 128 x 128, 8 waves, LDS-DMA with eight stages: one-round launches of small batches in the 16-bit modes
+      if constexpr (PR != PREC_F32) launch_cfg<128, 128, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
+      break;
+    case 11:
+      if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves
+      break;
+    case 13:
+      if constexpr (PR == PREC_F32) launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 64-row tile
+      break;
+    default: launch_cfg<128, 32, 2, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+  }
+}
+inline void gemm_dispatch_tile_x3(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1) {
+  switch (tile) {
+    case 2: launch_cfg_x3<128, 64, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 4: launch_cfg_x3<128, 32, 4, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 5: launch_cfg_x3<128, 128, 4, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 6: launch_cfg_x3<128, 64, 4, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 8: launch_cfg_x3<128, 128, 4, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+    case 20: launch_cfg_x3<128, 128, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;     // 4 waves of 64 x 64
+    case 21: launch_cfg_x3<128, 128, 2, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves: 64 x 64 x two K-groups
+    case 22: launch_cfg_x3<128, 256, 2, 4>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;     // 8 waves of 64 x 64, 256 rows
+    default: launch_cfg_x3<128, 32, 2, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
+  }
+}
+// Process-wide switch of the split-fp32 contractions (STTS_NO_X3=1: every fp32 contraction on v_mfma_f32_32x32x2_f32, the path of rounds 1-3)
+inline bool x3_enabled() {
+  static const bool on = !(getenv("STTS_NO_X3") && atoi(getenv("STTS_NO_X3")) != 0);
+  return on;
+}
+
 // npad: padded cout of the packed weight (multiple of 128).  max_rows: longest utterance (rows).
 // Tile choice: 128x128 when that already fills the chip, else smaller row tiles for more workgroups.
 inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, int force_tile = 0) {
@@ -1088,7 +1245,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // 16-bit activation rows, store epilogue, at least ~one 256 x 256 tile per CU: the persistent LDS-DMA kernel (gemm16.hip.h).
   // force_tile 19 selects it whatever the size (tests), any other forced tile keeps the launch on conv_gemm_f32.
   if (force_tile == 19 || (force_tile == 0 && gemm16_will_run(a, epi, npad, n_utt))) {
-    if (gemm16_eligible(a, epi, npad)) return launch_conv_gemm16<0>(st, a, npad, n_utt);
+    if (gemm16_eligible(a, epi, npad)) return launch_conv_gemm16_main(st, a, npad, n_utt);
   }
   STTS_CHECK(!a.stat_part, "conv_gemm: output statistics (stat_part) exist only in conv_gemm16_kernel's epilogue: ask gemm16_will_run first");
   STTS_CHECK(force_tile != 19, "conv_gemm: tile 19 (conv_gemm16_kernel) needs 16-bit activation rows, a store epilogue, channels in multiples of 64 and cout padded to 256");
@@ -1136,6 +1293,14 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     return p;
   };
   const long blocks128 = mt * row_tiles(128);
+  // split fp32: fp32 call, every segment carries the three bf16 planes of its weight, epilogue with a split instantiation
+  bool x3 = a.prec == PREC_F32 && x3_enabled() && (epi == EPI_STORE || epi == EPI_PRIOR) && !a.x16;
+  for (int i = 0; i < a.nseg; ++i) x3 = x3 && a.seg[i].W16 != nullptr && a.seg[i].w16_plane > 0 && 6 * a.seg[i].w16_plane + 2L * 128 * a.seg[i].ntaps * a.seg[i].kc < (1L << 32);
+  if (force_tile >= 100) {  // tests / tools: 100 + t = tile t on the f32 matrix cores whatever the switch says
+    x3 = false;
+    force_tile -= 100;
+  }
+  if (force_tile != 0 && !((force_tile >= 2 && force_tile <= 6) || force_tile == 8 || (force_tile >= 20 && force_tile <= 22))) x3 = false;  // a forced tile without a split form (LDS-DMA tiles)
   int tile = force_tile;
   const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
   Plan plan;
@@ -1174,9 +1339,10 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   STTS_CHECK(!((tile == 14 || tile == 15) && (a.prec == PREC_F32 || epi != EPI_STORE)), "conv_gemm: tiles 14 / 15 are for 16-bit operand store launches");
   STTS_CHECK(!((tile >= 16 && tile <= 18) && (a.prec == PREC_F32 || epi != EPI_STORE || !a.x16)), "conv_gemm: tiles 16 - 18 are for 16-bit activation rows, store epilogue");
   STTS_CHECK((tile != 14 && tile != 16) || npad % 256 == 0, "conv_gemm: tiles 14 / 16 need cout padded to 256");
-  const int bn = (tile >= 14 && tile <= 17) ? 256 : (tile == 5 || tile == 8 || tile == 11 || tile == 18) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
+  STTS_CHECK(!(tile >= 20 && tile <= 22) || x3, "conv_gemm: tiles 20 - 22 exist for the split-fp32 contractions only");
+  const int bn = ((tile >= 14 && tile <= 17) || tile == 22) ? 256 : (tile == 5 || tile == 8 || tile == 11 || tile == 18 || tile == 20 || tile == 21) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
   if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
-  if (tile == 8) {
+  if (tile == 8 || tile == 21) {
     plan.full_rt = row_tiles(bn);
     plan.rem_rt = 0;
   }
@@ -1189,7 +1355,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // Block-level split-K for launches that cannot fill the chip (phoneme-rate layers, B = 1): one wave's MFMA chain over
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
   int main_ksp = 1;
-  if (splittable && tile != 8 && plan.rem_rt == 0) {
+  if (splittable && tile != 8 && tile != 21 && plan.rem_rt == 0) {
     const long blocks = plan.full_rt * mt;
     // (16-bit operands: a contraction that already has one tile per CU is shorter than the reduce pass it would add)
     // K iterations a slice must keep: 4; 8 once the launch has half a chip of blocks anyway (a 16-iteration contraction over 128-256 blocks cut in
@@ -1227,42 +1393,11 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       e1 = prof.next();
       prof.add("conv_gemm_f32", 0, flops * (double)ntiles / (double)all_rt, flops * (double)ntiles / (double)all_rt, 0.0);
     }
-    auto dispatch = [&](auto prec_tag) {
-      constexpr int PR = decltype(prec_tag)::value;
-      switch (tile) {
-        case 2: launch_cfg<128, 64, 2, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
-        case 4: launch_cfg<128, 32, 4, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 32-row tile, 4 waves of one 32x32 tile each
-        case 5: launch_cfg<128, 128, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves per block
-        case 6: launch_cfg<128, 64, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // 8 waves, 64-row tiles
-        case 8: launch_cfg<128, 128, 4, 2, 2, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 16 waves: 8 positions x 2 K-groups
-        case 14:  // 256 cout x 256 rows, 8 waves of 64 x 128 (8 accumulator tiles): 16-bit operands at large batches, where the
-                  // 128x128 loop is bound by L2 -> LDS staging (47 B/clk/CU needed); this tile needs 31
-          if constexpr (PR != PREC_F32) launch_cfg<256, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
-          break;
-        case 15:
-          if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
-          break;
-        case 16:  // tiles 14 / 15 with LDS-DMA staging (global_load_lds_dwordx4, three stages): 16-bit activation rows only
-          if constexpr (PR != PREC_F32) launch_cfg<256, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
-          break;
-        case 17:
-          if constexpr (PR != PREC_F32) launch_cfg<128, 256, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
-          break;
-        case 18:  // 128 x 128, 8 waves, LDS-DMA with eight stages: one-round launches of small batches in the 16-bit modes
-          if constexpr (PR != PREC_F32) launch_cfg<128, 128, 4, 2, 1, true, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1);
-          break;
-        case 11:
-          if constexpr (PR == PREC_F32) launch_cfg<128, 128, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 8 waves
-          break;
-        case 13:
-          if constexpr (PR == PREC_F32) launch_cfg<128, 64, 4, 2, 1, true>(st, as, epi, npad, n_utt, max_rows, e0, e1);  // LDS-DMA staging, 64-row tile
-          break;
-        default: launch_cfg<128, 32, 2, 1, 1, false, PR>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
-      }
-    };
-    if (a.prec == PREC_BF16) dispatch(std::integral_constant<int, PREC_BF16>{});
-    else if (a.prec == PREC_F16) dispatch(std::integral_constant<int, PREC_F16>{});
-    else dispatch(std::integral_constant<int, PREC_F32>{});
+    // the kernels live in one translation unit per operand form (csrc/gemm_tu_*.hip, compiled in parallel)
+    if (x3) gemm_dispatch_x3(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+    else if (a.prec == PREC_BF16) gemm_dispatch_bf16(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+    else if (a.prec == PREC_F16) gemm_dispatch_f16(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+    else gemm_dispatch_f32(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
     if (ksp > 1 && a.defer && tile0 == 0 && ntiles == all_rt) {
       *a.defer = SplitInfo{part, ksp, a.rows_total, npad};
     } else if (ksp > 1) {
@@ -1290,6 +1425,25 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   STTS_HIP(hipGetLastError());
   return 0;
 }
+#ifdef STTS_GEMM_TU_FORM
+#if STTS_GEMM_TU_FORM == 0
+void gemm_dispatch_f32(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1) {
+  gemm_dispatch_tile<PREC_F32>(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+}
+#elif STTS_GEMM_TU_FORM == 1
+void gemm_dispatch_bf16(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1) {
+  gemm_dispatch_tile<PREC_BF16>(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+}
+#elif STTS_GEMM_TU_FORM == 2
+void gemm_dispatch_f16(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1) {
+  gemm_dispatch_tile<PREC_F16>(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+}
+#elif STTS_GEMM_TU_FORM == 3
+void gemm_dispatch_x3(hipStream_t st, const GemmArgs& as, int tile, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0, hipEvent_t e1) {
+  gemm_dispatch_tile_x3(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);
+}
+#endif
+#endif  // STTS_GEMM_TU_FORM
 #endif  // STTS_GEMM_NO_LAUNCHER
 
 }  // namespace stts

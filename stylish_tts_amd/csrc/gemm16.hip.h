@@ -549,4 +549,8 @@ inline int launch_conv_gemm16(hipStream_t st, const GemmArgs& a, int npad, int n
   return 0;
 }
 
+#ifdef STTS_GEMM16_TU
+int launch_conv_gemm16_main(hipStream_t st, const GemmArgs& a, int npad, int n_utt) { return launch_conv_gemm16<0>(st, a, npad, n_utt); }
+#endif
+
 }  // namespace stts

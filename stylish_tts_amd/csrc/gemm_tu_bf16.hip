@@ -1,0 +1,3 @@
+// Translation unit of the conv_gemm_f32 instantiations for one operand form (gemm.hip.h: gemm_dispatch_bf16); built in parallel with the others.
+#define STTS_GEMM_TU_FORM 1
+#include "gemm.hip.h"

@@ -31,7 +31,8 @@ struct HostTensor {
 
 struct PackedConv {
   float* W = nullptr;
-  unsigned short* W16 = nullptr;  // bf16 / fp16 copy (16-bit operand modes), same layout
+  unsigned short* W16 = nullptr;  // bf16 / fp16 copy (16-bit operand modes), same layout; fp32 mode: the three bf16 planes of the exact split (gemm.hip.h, PREC_X3)
+  long w16_plane = 0;             // fp32 mode: elements between two of those planes (0: no split form)
   int prec = 0;                   // PREC_* the copy was rounded to
   float* bias = nullptr;
   int npad = 0, N = 0, kc = 0, ntaps = 1;
@@ -143,6 +144,8 @@ struct stts_ctx {
   std::mutex side_mu;
   int ready = 0;  // STTS_W_* components finalized
   int prec = 0;   // contraction operand precision (stts::PREC_*), fixed before the first finalize
+  bool allow_x3 = true;  // false: STTS_PREC_F32_NATIVE - fp32 contractions on the f32 matrix cores only
+  bool pack_x3 = true;  // fp32 mode: pack_rows also writes the three bf16 planes of every weight (split-fp32 contractions, gemm.hip.h PREC_X3); off while the phoneme-rate / CFM models are packed
   int kc_align = 32;  // input channels of a packed conv are padded to this (64 while the frame path is packed for a 16-bit mode: conv_gemm16_kernel's K tile)
   // shared tables
   float* hann = nullptr;      // periodic Hann(win)
@@ -257,6 +260,19 @@ inline unsigned short f32_to_bf16(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+inline float bf16_to_f32(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// exact three-term bf16 split of an fp32 value (gemm.hip.h, PREC_X3): f = p0 + p1 + p2, every term the RNE bf16 of what is left
+inline void split3_host(float f, unsigned short* p0, unsigned short* p1, unsigned short* p2) {
+  *p0 = f32_to_bf16(f);
+  const float r1 = f - bf16_to_f32(*p0);
+  *p1 = f32_to_bf16(r1);
+  *p2 = f32_to_bf16(r1 - bf16_to_f32(*p1));
+}
 inline unsigned short f32_to_f16(float f) {
   const _Float16 h = (_Float16)f;  // IEEE RNE, saturates to inf
   unsigned short r;
@@ -280,8 +296,14 @@ inline int pack_rows(stts_ctx* c, const HostTensor& w, const HostTensor* bias, c
   STTS_TRY(dev_upload(c, pb, &out->bias));
   out->prec = c->prec;
   out->W16 = nullptr;
-  if (c->prec != PREC_F32) {
-    std::vector<unsigned short> h(pw.size());
+  out->w16_plane = 0;
+  if (c->prec != PREC_F32 || (c->allow_x3 && c->pack_x3 && x3_enabled())) {
+    const bool split = c->prec == PREC_F32;
+    std::vector<unsigned short> h(pw.size() * (split ? 3 : 1));
+    if (split) {
+      out->w16_plane = (long)pw.size();
+      for (size_t i = 0; i < pw.size(); ++i) split3_host(pw[i], &h[i], &h[pw.size() + i], &h[2 * pw.size() + i]);
+    } else
     for (size_t i = 0; i < pw.size(); ++i) h[i] = c->prec == PREC_BF16 ? f32_to_bf16(pw[i]) : f32_to_f16(pw[i]);
     void* d = nullptr;
     STTS_HIP(hipMalloc(&d, h.size() * sizeof(unsigned short)));
@@ -770,6 +792,7 @@ inline GemmArgs gemm_args(const Seg& s) {
     if (same) { a.uniform_len = len; a.uniform_lo0 = s.host[0]; }
   }
   a.alpha = 1.0f;
+  a.xaff_slope = 0.2f;
   a.zeros = zero_page();
   return a;
 }
@@ -778,6 +801,7 @@ inline void set_seg(GemmArgs& a, int i, const float* X, int ldx, int xcol0, cons
   g.X = X;
   g.W = w.W;
   g.W16 = w.W16;
+  g.w16_plane = w.w16_plane;
   if (i == 0) a.prec = w.prec;
   g.w_utt_stride = 0;
   g.ldx = ldx;
@@ -1689,12 +1713,22 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
     a.sumsq_part = part; a.ld_ss = inter; a.ss_stride = ss_stride;
     STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, B.pw1.npad, s.n_utt, ml));
     STTS_LAUNCH_PROF("grn_gx_kernel", (size_t)s.n_utt * ss_stride * inter * 4, grn_gx_kernel, dim3(ceil_div(inter, 32), s.n_utt), dim3(256), st, part, inter, ss_stride, s.dev, inter, gscale, inter);
-    launch_scale_weight(st, dim3(128, s.n_utt), B.pw2.prec, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     GemmArgs b = gemm_args(s);
     set_seg(b, 0, U, inter, 0, B.pw2);
+    if (B.pw2.prec == PREC_F32 && B.pw2.w16_plane > 0 && x3_enabled()) {
+      // split fp32: GRN's per-(utterance, channel) factor scales the ACTIVATION while pwconv2's tile is staged (the contraction's input affine with
+      // slope 1) instead of a per-utterance copy of the weight: the shared split planes of W stay valid and the scale_weight pass is gone
+      hipLaunchKernelGGL(grn_xaff_kernel, dim3(s.n_utt), dim3(256), 0, st, gscale, inter, B.grn_gamma, w2u, B.pw2.kc, inter);
+      b.xaff = w2u;
+      b.ld_xaff = B.pw2.kc;
+      b.xaff_slope = 1.0f;
+    } else {
+    launch_scale_weight(st, dim3(128, s.n_utt), B.pw2.prec, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     b.seg[0].W = w2u;
     b.seg[0].W16 = reinterpret_cast<const unsigned short*>(w2u);
+    b.seg[0].w16_plane = 0;
     b.seg[0].w_utt_stride = (long)B.pw2.npad * B.pw2.kc;
+    }
     b.x16 = p16 != 0;
     b.N = h; b.bias = B.pw2.bias; b.Y = nxt; b.ldy = h; b.R = cur; b.ldr = h;
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.pw2.npad, s.n_utt, ml));

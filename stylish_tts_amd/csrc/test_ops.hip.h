@@ -12,9 +12,11 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   API_BEGIN
   hipStream_t st = (hipStream_t)stream;
   STTS_CHECK(ldx % 32 == 0 && ldx >= cin, "op_conv1d: ldx must be a multiple of 32 covering cin");
-  STTS_CHECK(precision >= 0 && precision <= 2, "precision must be STTS_PREC_F32, _BF16 or _F16");
+  // precision 0: fp32, split-fp32 contraction (PREC_X3, the default form); 3: fp32 on the f32 matrix cores (STTS_PREC_F32_NATIVE)
+  STTS_CHECK(precision >= 0 && precision <= 3, "precision must be STTS_PREC_F32, _BF16, _F16 or _F32_NATIVE");
   stts_ctx tmp;  // only for allocation bookkeeping
-  tmp.prec = precision;
+  tmp.prec = precision == 3 ? 0 : precision;
+  tmp.allow_x3 = precision != 3;
   struct FreeAll {  // every exit path (including the early STTS_TRY / STTS_CHECK returns) waits for the stream and frees the temporaries
     stts_ctx& t;
     hipStream_t st;
@@ -31,7 +33,7 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   if (bias_host) b.data.assign(bias_host, bias_host + cout);
   Seg s{n_utt, seg_off_host, seg_off_dev};
   if (force_tile == -4) {  // the Winograd F(6, k) form (k = 3 or 7, dilation 1): winograd.hip.h
-    STTS_CHECK(dil == 1 && precision == 0, "op_conv1d: the Winograd form is fp32, dilation 1");
+    STTS_CHECK(dil == 1 && (precision == 0 || precision == 3), "op_conv1d: the Winograd form is fp32, dilation 1");
     WinoConv wc;
     STTS_TRY(pack_winograd(&tmp, w, bias_host ? &b : nullptr, 0, cin, cout, &wc));
     float* scratch = nullptr;
@@ -49,7 +51,7 @@ int stts_op_conv1d(void* stream, int n_utt, const int32_t* seg_off_host, const i
   set_seg(a, 0, x, ldx, 0, pc, (k - 1) / 2, dil);
   a.N = cout; a.bias = pc.bias; a.Y = y; a.ldy = ldy; a.act = act;
   if (force_tile >= 100) {  // tests: the contraction reads 16-bit activation rows (rounded copy of x), tile = force_tile - 100
-    STTS_CHECK(precision != 0, "op_conv1d: 16-bit activation rows need a 16-bit operand mode");
+    STTS_CHECK(precision == 1 || precision == 2, "op_conv1d: 16-bit activation rows need a 16-bit operand mode");
     unsigned short* x16 = nullptr;
     STTS_HIP(hipMalloc(&x16, (size_t)s.rows() * ldx * sizeof(unsigned short)));
     tmp.allocs.push_back(x16);
@@ -133,12 +135,14 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
   for (int i = 0; i <= n_utt; ++i) h[i] = i * rows_per_utt;
   STTS_HIP(hipMemcpy(so, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
   // pseudo-random fill (zeros would flatter the clock: guide §5.4 rule 25)
+  std::vector<float> hw((size_t)npad * k * kc);
   {
     std::vector<float> t((size_t)std::max<long>(R * kc, (long)npad * k * kc));
     uint32_t s = 12345;
     for (auto& v : t) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
     STTS_HIP(hipMemcpy(X, t.data(), R * kc * sizeof(float), hipMemcpyHostToDevice));
     STTS_HIP(hipMemcpy(W, t.data(), (size_t)npad * k * kc * sizeof(float), hipMemcpyHostToDevice));
+    std::copy(t.begin(), t.begin() + hw.size(), hw.begin());
     STTS_HIP(hipMemset(B, 0, npad * sizeof(float)));
   }
   PackedConv pc;
@@ -153,10 +157,19 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
     pc.W16 = W16;
     pc.prec = (tune & 128) ? PREC_BF16 : PREC_F16;
   }
+  if (tune & 2048) {  // bit 11: split-fp32 contraction (the three bf16 planes of W)
+    std::vector<unsigned short> h3(hw.size() * 3);
+    for (size_t i = 0; i < hw.size(); ++i) split3_host(hw[i], &h3[i], &h3[hw.size() + i], &h3[2 * hw.size() + i]);
+    STTS_HIP(hipMalloc(&W16, h3.size() * 2));
+    STTS_HIP(hipMemcpy(W16, h3.data(), h3.size() * 2, hipMemcpyHostToDevice));
+    pc.W16 = W16;
+    pc.w16_plane = (long)hw.size();
+  }
   Seg s{n_utt, h.data(), so};
   GemmArgs a = gemm_args(s);
   set_seg(a, 0, X, kc, 0, pc);
   a.N = cout; a.bias = B; a.Y = Y; a.ldy = ldy; a.tune = tune & 63;
+  if ((tune & 2048) && !x3_enabled()) return stts::fail("split-fp32 contractions are switched off (STTS_NO_X3)");
   unsigned short* X16 = nullptr;
   if ((tune & 1024) && (tune & 384)) {  // bit 10: 16-bit activation rows (X rounded once, outside the timed launches)
     STTS_HIP(hipMalloc(&X16, R * kc * sizeof(unsigned short)));

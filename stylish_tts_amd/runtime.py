@@ -72,10 +72,11 @@ class CapacityOverflow(RuntimeError):
 class HipModel:
     """Owns a stts_ctx.  weights: {module name: {state_dict key: array}} for the five inference modules."""
 
-    PRECISIONS = {"f32": 0, "bf16": 1, "f16": 2}
+    PRECISIONS = {"f32": 0, "bf16": 1, "f16": 2, "f32_native": 3}
 
     def __init__(self, cfg=None, device: int = 0, precision: str = "f32"):
-        """precision: operand precision of the contractions ("f32" = the reference's arithmetic; "bf16" / "f16" round
+        """precision: operand precision of the contractions ("f32" = the reference's arithmetic, fp32 products formed from exact
+        three-term bf16 splits on the bf16 matrix cores; "f32_native" = the same on the f32 matrix cores; "bf16" / "f16" round
         the matrix-core operands, fp32 accumulate; include/stylish_hip.h:stts_set_precision)."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
@@ -91,7 +92,7 @@ class HipModel:
         self.precision = precision
         _lib.check(self.lib.stts_set_precision(self.ctx, self.PRECISIONS[precision]))
         # row stride of the harmonic spectra = the prior convs' packed input width: 1025 bins padded to 32 (fp32) or 64 (16-bit modes)
-        self.har_ld = N_BINS_LD if precision == "f32" else 1088
+        self.har_ld = N_BINS_LD if precision in ("f32", "f32_native") else 1088
         # grow-only workspaces, one per launch stream (stages issued on different streams may run concurrently)
         self._ws: Dict[int, torch.Tensor] = {}
         self._pws: Dict[int, torch.Tensor] = {}
