@@ -349,6 +349,16 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     bool aff;
   };
   RegSet rsA, rsB;
+  // split fp32: a K iteration is 3/8 of the fp32 one in matrix-pipe time (~0.7 us per 128 x 128 x 32), shorter than a loaded-memory round trip, so tiles
+  // are fetched FOUR iterations ahead into four register sets
+  // (measured, B = 8: no gain on the 128 x 128 tile - pwconv1 95 -> 98 us, decoder conv2 79 -> 78 - and a loss on the 128 x 64 tile, whose 128
+  //  registers become 162 and halve its waves per SIMD: 84 -> 96 us; the loop is not waiting for its loads.  Kept behind a build flag.)
+#ifdef STTS_X3_DEEP
+  constexpr bool DEEP = X3 && KSPLIT == 1 && BN <= 128;
+#else
+  constexpr bool DEEP = false;
+#endif
+  RegSet rsC, rsD;
   // Addressing: uniform (scalar) base pointers + 32-bit per-thread byte offsets, so the loads use the saddr form and the
   // per-iteration vector arithmetic is a clamp, a multiply and an add per X row (the W offsets are loop invariant).
   // Offsets are relative to the utterance / the weight tile, hence always < 2^31 bytes.
@@ -546,20 +556,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     const int slot = 2 * kk + lh;
     if constexpr (X3) {
       f32x4 xa[TR][3], wb[TC][3];
+      const bool nord = ablate(32);  // timing-only ablation: operands are not read from LDS
 #pragma unroll
       for (int i = 0; i < TR; ++i) {
         const int r = wn * WR + i * 32 + l31;
         const int o = r * 4 + (slot ^ ((r >> 2) & 3));
 #pragma unroll
-        for (int p = 0; p < 3; ++p) xa[i][p] = Xs[o + p * PLANE];
+        for (int p = 0; p < 3; ++p) {
+          if (!nord) xa[i][p] = Xs[o + p * PLANE];
+          else xa[i][p] = f32x4{(float)r, (float)kk, (float)p, 0.f};
+        }
       }
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
         const int c = wm * WC + j * 32 + l31;
         const int o = c * 4 + (slot ^ ((c >> 2) & 3));
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wb[j][p] = Ws[o + p * PLANE];
+        for (int p = 0; p < 3; ++p) {
+          if (!nord) wb[j][p] = Ws[o + p * PLANE];
+          else wb[j][p] = f32x4{(float)c, (float)kk, (float)p, 0.f};
+        }
       }
+      if (ablate(1)) return;  // timing-only ablation: no MFMAs
       // the six products with p + q <= 2, smallest first (the accumulator takes the 2^-16 terms before the 2^-8 and the leading ones)
 #pragma unroll
       for (int i = 0; i < TR; ++i)
@@ -733,7 +751,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   gload(rsA);  // tile 0
   lstore(rsA, 0);
   gload(rsB);  // tile 1
-  gload(rsA);  // tile 2   (the cursor clamps at the last tile, extra fetches are harmless re-loads)
+  if constexpr (DEEP) {
+    gload(rsC);  // tile 2
+    gload(rsD);  // tile 3
+  }
+  gload(rsA);  // tile 2 (DEEP: 4)  (the cursor clamps at the last tile, extra fetches are harmless re-loads)
   __syncthreads();
   stamp(1);
 
@@ -771,7 +793,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     }
     if (!ablate(2)) __syncthreads();
   };
-  {
+  if constexpr (DEEP) {
+    // iteration `it` moves tile it + 1 (requested during iteration it - 4) into LDS and requests tile it + 5 into the freed set
+    int it = 0;
+    for (; it + 3 < total; it += 4) {
+      iter(it, rsB);
+      iter(it + 1, rsC);
+      iter(it + 2, rsD);
+      iter(it + 3, rsA);
+    }
+    if (it < total) iter(it, rsB);
+    if (it + 1 < total) iter(it + 1, rsC);
+    if (it + 2 < total) iter(it + 2, rsD);
+  } else {
     int it = 0;
     for (; it + 1 < total; it += 2) {  // branch-free body: two iterations, one per register set
       iter(it, rsB);
@@ -1318,7 +1352,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       // keeps the matrix pipes busier than 8 waves do (118 vs 125.5 us) and beats cutting K over two blocks plus the
       // reduce pass (131 us)
       // (fp32 only: with 16-bit operands the loop is staging-bound and 8 waves are faster, 34 vs 40 us)
-      if (tile == 5 && blocks128 <= kCUs && a.prec == PREC_F32) tile = 8;
+      // (split fp32: the 8-wave tile is the faster one there too, and the 16-wave tile's 128-register budget spills with the input affine)
+      if (tile == 5 && blocks128 <= kCUs && a.prec == PREC_F32 && !x3) tile = 8;
     }
   }
   if (force_tile == 0 && a.prec != PREC_F32 && a.x16 && epi == EPI_STORE) {
@@ -1362,7 +1397,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     // two gained less than its reduce pass costs: CFM estimator 8 x 800 frames 7.00 -> 6.82 ms; launches with fewer blocks still gain from the cut)
     static const int min_it_env = getenv("STTS_SPLITK_MIN_ITERS") ? std::max(1, atoi(getenv("STTS_SPLITK_MIN_ITERS"))) : 0;  // experiments
     const int min_it = min_it_env ? min_it_env : (blocks >= 128 ? 8 : 4);
-    main_ksp = (int)std::min<long>(8, std::min<long>(iters / min_it, (a.prec == PREC_F32 ? 512 : 255) / std::max<long>(blocks, 1)));
+    // (fp32 on the f32 matrix cores: launches of 128-256 blocks take the 16-wave tile above, so 512 never cuts them; split fp32: like the 16-bit forms)
+    main_ksp = (int)std::min<long>(8, std::min<long>(iters / min_it, ((a.prec == PREC_F32 && !x3) ? 512 : 255) / std::max<long>(blocks, 1)));
     if (main_ksp < 2) main_ksp = 1;
   }
   float* part = nullptr;

@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/x3
+B=8 TILES=5,x5,x6,x2,x20,x22 timeout -k 10 300 python tools/gemm_bench.py > gpurun_out/x3/gemm_b8_v2.log 2>&1 || { tail gpurun_out/x3/gemm_b8_v2.log; exit 1; }
+cat gpurun_out/x3/gemm_b8_v2.log
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-traffic > gpurun_out/x3/bench_x3_v2.json 2> gpurun_out/x3/bench_x3_v2.err || { tail gpurun_out/x3/bench_x3_v2.err; exit 1; }
+python - <<'P'
+import json
+d=json.loads(open("gpurun_out/x3/bench_x3_v2.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"], [ (k["kernel"],k["ms_per_step"]) for k in d["roofline"]["contraction_kernels"]])
+P
+bash tools/prof_one.sh x3v2 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-legs | head -16
