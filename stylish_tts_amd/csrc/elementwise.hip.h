@@ -1012,6 +1012,28 @@ __global__ void __launch_bounds__(256) cast_rows_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(Y + r * ldy + c0) = out;
   }
 }
+// fp32 rows -> the three bf16 planes of the exact split (gemm.hip.h, PREC_X3): Y[p][r][c], planes `plane` elements apart, zeros beyond `cols`
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ X, int ldx, int cols, unsigned short* __restrict__ Y, int ldy, long plane, int width, long rows) {
+  const int q = width / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * q; i += (long)gridDim.x * 256) {
+    const long r = i / q;
+    const int c0 = (int)(i % q) * 4;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = c0 + e < cols ? X[r * ldx + c0 + e] : 0.0f;
+    u32x2 p0, p1, p2;
+    split3_bf16(v, p0, p1, p2);
+    unsigned short* o = Y + r * ldy + c0;
+    *reinterpret_cast<u32x2*>(o) = p0;
+    *reinterpret_cast<u32x2*>(o + plane) = p1;
+    *reinterpret_cast<u32x2*>(o + 2 * plane) = p2;
+  }
+}
+inline void launch_split_rows(hipStream_t st, const float* X, int ldx, int cols, unsigned short* Y, int ldy, long plane, long rows, int width = 0) {
+  if (width == 0) width = ldy;
+  const dim3 grid((unsigned)std::min<long>(4096, std::max<long>(1, (rows * (width / 4) + 255) / 256)));
+  STTS_LAUNCH_PROF("split_rows_kernel", (size_t)rows * (cols * 4 + width * 6), split_rows_kernel, grid, dim3(256), st, X, ldx, cols, Y, ldy, plane, width, rows);
+}
 // width: columns written per row (a multiple of 8; 0 = the whole row stride ldy)
 inline void launch_cast_rows(hipStream_t st, int prec, const float* X, int ldx, int cols, unsigned short* Y, int ldy, long rows, int width = 0) {
   if (width == 0) width = ldy;

@@ -49,6 +49,7 @@ struct GemmSeg {
   const float* W;     // packed [Npad][ntaps][kc]
   const unsigned short* W16;  // the same tensor rounded to bf16 / fp16 (16-bit operand modes); PREC_X3: the three bf16 planes of the exact split
   long w16_plane;     // PREC_X3: elements between two planes of W16 (0: this weight has no split form)
+  long x_plane;       // PREC_X3 with pre-split activations (GemmArgs::x16): X points to the first of three bf16 planes [rows, ldx], x_plane elements apart
   long w_utt_stride;  // floats between per-utterance copies of W (0: shared)
   int ldx, xcol0, kc, ntaps, dil, pad;
   int kreal;  // un-padded input channels (host side: algorithmic FLOP accounting only)
@@ -201,12 +202,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   constexpr bool B16 = PREC != PREC_F32;
   constexpr bool X3 = PREC == PREC_X3;  // split fp32: three bf16 planes per operand, six MFMAs per (tile, 16 channels)
   constexpr int NPL = X3 ? 3 : 1;
-  static_assert(!X3 || (!GLDS && !X16), "split fp32: activations are fp32 rows, split on the register staging path");
+  static_assert(!X3 || !GLDS || X16, "split fp32: fp32 activation rows are split on the register staging path; LDS-DMA needs pre-split planes");
   static_assert(!(B16 && GLDS) || X16, "LDS-DMA staging of 16-bit operands needs 16-bit activation rows (nothing converts on the way)");
   static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT");
   constexpr int WR = BN / WARPS_N, WC = BM / WARPS_M;
   constexpr int TR = WR / 32, TC = WC / 32;
-  constexpr int XL = X16 ? (BN * 4 + NT - 1) / NT : BN * 8 / NT;  // 16-byte X loads per thread per tile (16-bit rows: 4 per 32 channels)
+  constexpr int XL = X16 ? (BN * 4 * NPL + NT - 1) / NT : BN * 8 / NT;  // 16-byte X loads per thread per tile (16-bit rows: 4 per 32 channels and plane)
   constexpr int WL = B16 ? (BM * 4 * NPL + NT - 1) / NT : BM * 8 / NT;  // 16-byte W loads per thread per tile
   static_assert(WR % 32 == 0 && WC % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert((X16 || (BN * 8) % NT == 0) && (B16 || (BM * 8) % NT == 0), "tile loads must divide over the block");
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // size); the 16-bit LDS-DMA path keeps three stages so that tiles are requested two iterations ahead
   // (three for the 256-row tiles; EIGHT for the 128 x 128 tile of small batches, whose K iteration - four MFMAs per wave - is far
   //  shorter than a memory round trip: with tiles requested two iterations ahead that loop ran at one iteration per ~0.6 us)
-  constexpr int NSTAGE = (B16 && GLDS) ? ((BM + BN) <= 256 ? 8 : 3) : 2;
+  constexpr int NSTAGE = (B16 && GLDS) ? (X3 ? 3 : ((BM + BN) <= 256 ? 8 : 3)) : 2;
   // 16-byte slots per tile row and stage: fp32 8 (32 channels); 16-bit 4 per plane; split fp32: planes [p][X rows | W rows][4]
   constexpr int SLOTS = X3 ? 12 : ((B16 && KSPLIT == 1) ? 4 : 8);
   constexpr int PLANE = (BN + BM) * 4;      // 16-bit layouts: f32x4 slots of one plane of one stage
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // Offsets are relative to the utterance / the weight tile, hence always < 2^31 bytes.
   unsigned woff[WL];
   const int len = hi - lo, rel0 = row0 - lo;
-  long g_wplane = X3 ? a.seg[0].w16_plane : 0;
+  long g_wplane = X3 ? a.seg[0].w16_plane : 0, g_xplane = (X3 && X16) ? a.seg[0].x_plane : 0;
   auto seg_offsets = [&]() {
     const int wrow = g_ntaps * g_kc;
 #pragma unroll
@@ -392,10 +393,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NT;
-      const int r = X16 ? idx >> 2 : idx >> 3, sl = X16 ? idx & 3 : idx & 7;
+      const int pl = (X16 && X3) ? min(idx / (BN * 4), 2) : 0, idp = (X16 && X3) ? idx % (BN * 4) : idx;  // pre-split planes: (plane, row, 8 channels)
+      const int r = X16 ? idp >> 2 : idx >> 3, sl = X16 ? idp & 3 : idx & 7;
       const int rel = (hot ? 0 : rel0) + r + shift;
       const int crel = min(max(rel, 0), len - 1);
       const unsigned off = X16 ? (unsigned)((crel * g_ldx + sl * 8) * 2) : (unsigned)((crel * g_ldx + sl * 4) * 4);
+      if constexpr (X16 && X3) rs.x[i] = *reinterpret_cast<const f32x4*>(xb + (long)pl * g_xplane * 2 + off);
+      else
       rs.x[i] = *reinterpret_cast<const f32x4*>(xb + off);
       rs.ok[i] = rel >= 0 && rel < len;
     }
@@ -424,7 +428,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
-        if constexpr (X3) g_wplane = n.w16_plane;
+        if constexpr (X3) { g_wplane = n.w16_plane; g_xplane = n.x_plane; }
         seg_offsets();
       }
     }
@@ -452,7 +456,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
         const int idx = tid + i * NT;
-        if constexpr (X3) {  // four fp32 channels -> their place in each of the three bf16 planes
+        if constexpr (X3 && X16) {  // pre-split planes: 8 channels of one plane go straight into their slot
+          const int pl = idx / (BN * 4), idp = idx % (BN * 4), r = idp >> 2, sl = idp & 3;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if (BN * 12 % NT == 0 || idx < BN * 12) Xs[pl * PLANE + r * 4 + (sl ^ ((r >> 2) & 3))] = rs.ok[i] ? rs.x[i] : z;
+        } else if constexpr (X3) {  // four fp32 channels -> their place in each of the three bf16 planes
           const int r = idx >> 3, sl = idx & 7;
           u32x2 p0, p1, p2;
           split3_bf16(xin(rs, i), p0, p1, p2);
@@ -516,7 +524,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         gW = n.W + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         if constexpr (B16) gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
         g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
-        if constexpr (X3) g_wplane = n.w16_plane;
+        if constexpr (X3) { g_wplane = n.w16_plane; g_xplane = n.x_plane; }
         seg_offsets();
       }
     }
@@ -620,8 +628,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
     if constexpr (B16) {
       // 16-bit rows (64 bytes per tile row): one wave-instruction = 16 tile rows; three stages, tile it+2 is requested while tile it is
       // multiplied, and the wait before the barrier leaves that newest tile's requests in flight (vmcnt retires in order)
-      constexpr int NW = NT / 64, NI = (BN + BM) / 16, PER = NI / NW;
-      static_assert(NI % NW == 0 && BN % 16 == 0, "tile rows must divide over the waves");
+      constexpr int NW = NT / 64, NI1 = (BN + BM) / 16, NI = NI1 * NPL, PER = NI / NW;  // (split fp32: the three planes of the tile, one after the other)
+      static_assert((NI % NW == 0 || X3) && BN % 16 == 0, "tile rows must divide over the waves");
+      constexpr int PERC = (NI + NW - 1) / NW;  // (split fp32, 36 instructions over 8 waves: the last wave-instructions are issued twice - same bytes to the same place - so every wave counts the same vmcnt)
       const int wv = tid >> 6;
       auto issue = [&](int b) {
         const int shift = (tap - g_pad) * g_dil;
@@ -629,8 +638,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         const char* wb = reinterpret_cast<const char*>(gW16 + tap * g_kc + chunk * 32);
         const int wrow = g_ntaps * g_kc;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          const int inst = wv + q * NW;              // 16-row group of the combined [X rows | W rows] tile
+        for (int q = 0; q < PERC; ++q) {
+          const int instq = min(wv + q * NW, NI - 1);  // 16-row group of the combined [X rows | W rows] tile of plane pl
+          const int pl = instq / NI1, inst = instq % NI1;
           const int trow = inst * 16 + (lane >> 2);  // row in the combined tile
           const char* src;
           if (inst < BN / 16) {                      // wave-uniform
@@ -638,14 +648,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
             const int sslot = (lane & 3) ^ ((r >> 2) & 3);
             const int rel = rel0 + r + shift;
             const bool ok = rel >= 0 && rel < len;
-            src = ok ? xb + (unsigned)((rel * g_ldx + sslot * 8) * 2) : reinterpret_cast<const char*>(a.zeros);
+            src = ok ? xb + (long)pl * g_xplane * 2 + (unsigned)((rel * g_ldx + sslot * 8) * 2) : reinterpret_cast<const char*>(a.zeros);
           } else {
             const int n = trow - BN;
             const int sslot = (lane & 3) ^ ((n >> 2) & 3);
-            src = wb + (unsigned)((n * wrow + sslot * 8) * 2);
+            src = wb + (long)pl * g_wplane * 2 + (unsigned)((n * wrow + sslot * 8) * 2);
           }
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(lds + b * (BN + BM) * 4 + inst * 64), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void*)(lds + b * STG16 + pl * PLANE + inst * 64), 16, 0, 0);
         }
         const bool wrapt1 = tap + 1 >= g_ntaps;
         const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
@@ -659,11 +669,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
             gX = xbase(n);
             gW16 = n.W16 + (long)utt * n.w_utt_stride + (long)m0 * n.ntaps * n.kc;
             g_ldx = n.ldx; g_kc = n.kc; g_ntaps = n.ntaps; g_dil = n.dil; g_pad = n.pad;
+            if constexpr (X3) { g_wplane = n.w16_plane; g_xplane = n.x_plane; }
           }
         }
       };
       // wait until only the NSTAGE - 2 newest tiles' requests of this wave are outstanding: the next tile to multiply has landed
-      constexpr int INFLIGHT = (NSTAGE - 2) * PER;
+      (void)PER;
+      constexpr int INFLIGHT = (NSTAGE - 2) * PERC;
       static_assert(INFLIGHT >= 1 && INFLIGHT <= 63, "vmcnt immediate");
       auto wait_next_tile = [&]() {
         asm volatile("" ::: "memory");
@@ -764,9 +776,71 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   // into the freed register set.
   int return_guard = 0;
   (void)return_guard;
+  // split fp32 (one K-group): the MFMA operands of a 16-channel half are read from LDS one half AHEAD of the 6 x TR x TC MFMAs that consume
+  // them, into two named fragment sets - the reads of (tile it, half 1) fly under the MFMAs of half 0, those of (tile it + 1, half 0) are
+  // issued right after the barrier that publishes that tile and fly under the MFMAs of half 1.  With the reads in front of their own MFMAs the
+  // two waves of a SIMD, which the barrier keeps in lockstep, both sat out every LDS round trip with the matrix pipe idle.
+  // (measured, B = 8: 128 x 128 tile 78.7 -> 75.6 us on the decoder's conv2; the 128 x 64 tile loses its second block per CU to the 30 extra
+  //  registers, 82.6 -> 86.2 us, and the 256-row tile spills: only the 8-wave 128 x 128 tile is pipelined this way)
+  constexpr bool FPIPE = X3 && KSPLIT == 1 && BN == 128 && BM == 128 && WARPS_M * WARPS_N == 8 && !GLDS;
+  struct Frag {
+    f32x4 xa[TR][3], wb[TC][3];
+  };
+  Frag fA, fB;
+  auto frag_read = [&](int b, int kk, Frag& f) {
+    const f32x4* Xs = lds + b * STG16;
+    const f32x4* Ws = Xs + BN * 4;
+    const int slot = 2 * kk + lh;
+    const bool nord = ablate(32);
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int r = wn * WR + i * 32 + l31;
+      const int o = r * 4 + (slot ^ ((r >> 2) & 3));
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        if (!nord) f.xa[i][p] = Xs[o + p * PLANE];
+        else f.xa[i][p] = f32x4{(float)r, (float)kk, (float)p, 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      const int c = wm * WC + j * 32 + l31;
+      const int o = c * 4 + (slot ^ ((c >> 2) & 3));
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        if (!nord) f.wb[j][p] = Ws[o + p * PLANE];
+        else f.wb[j][p] = f32x4{(float)c, (float)kk, (float)p, 0.f};
+      }
+    }
+  };
+  auto frag_mma = [&](const Frag& f) {
+    if (ablate(1)) return;
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        acc[i][j] = mfma16<PREC>(f.xa[i][2], f.wb[j][0], acc[i][j]);
+        acc[i][j] = mfma16<PREC>(f.xa[i][0], f.wb[j][2], acc[i][j]);
+        acc[i][j] = mfma16<PREC>(f.xa[i][1], f.wb[j][1], acc[i][j]);
+        acc[i][j] = mfma16<PREC>(f.xa[i][1], f.wb[j][0], acc[i][j]);
+        acc[i][j] = mfma16<PREC>(f.xa[i][0], f.wb[j][1], acc[i][j]);
+        acc[i][j] = mfma16<PREC>(f.xa[i][0], f.wb[j][0], acc[i][j]);
+      }
+  };
+  if constexpr (FPIPE) frag_read(0, 0, fA);
   auto iter = [&](int it, RegSet& nset) {
     const f32x4* Xs = lds + (it & 1) * (BN + BM) * 8;
     const f32x4* Ws = Xs + BN * 8;
+    if constexpr (FPIPE) {
+      frag_read(it & 1, 1, fB);
+      frag_mma(fA);
+      if (!ablate(4)) lstore(nset, (it + 1) & 1);
+      if (!ablate(8)) gload(nset);
+      if (!ablate(2)) __syncthreads();  // (waits for this wave's LDS traffic first: its reads of this tile have landed before anybody overwrites the stage)
+      frag_read((it + 1) & 1, 0, fA);  // (after the last tile: a stale stage, read and dropped)
+      frag_mma(fB);
+      return;
+    }
     if constexpr (B16) {
       if constexpr (KSPLIT == 1) {
         mma_step16(it & 1, 0);
@@ -1195,10 +1269,15 @@ inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int
 }
 
 // split fp32 (PREC_X3): store and prior epilogues only; the flow's generic gate / couple / split-accumulate launches stay on the f32 matrix cores
-template <int BM, int BN, int WM, int WN, int KS = 1>
+template <int BM, int BN, int WM, int WN, int KS = 1, int X16MODE = 0>  // X16MODE 1: pre-split activation planes, register staging; 2: LDS-DMA staging
 inline void launch_cfg_x3(hipStream_t st, const GemmArgs& a, int epi, int npad, int n_utt, int max_rows, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   dim3 grid(npad / BM, ceil_div(max_rows, BN), n_utt * (a.ksplit > 1 ? a.ksplit : 1)), block(WM * WN * 64 * KS);
   if (a.compact) grid = dim3(npad / BM, a.tiles_y, a.ksplit > 1 ? a.ksplit : 1);
+  if constexpr (X16MODE != 0) {
+    if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, X16MODE == 2, PREC_X3, false, false, true>), grid, block, st, e0, e1, a);
+    else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, X16MODE == 2, PREC_X3, false, true, true>), grid, block, st, e0, e1, a);
+    return;
+  } else
   if (epi == EPI_PRIOR) {
     if constexpr (BM / WM >= 64) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, false, PREC_X3>), grid, block, st, e0, e1, a);
   } else if (a.xaff) {
@@ -1254,6 +1333,11 @@ inline void gemm_dispatch_tile_x3(hipStream_t st, const GemmArgs& as, int tile, 
     case 20: launch_cfg_x3<128, 128, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;     // 4 waves of 64 x 64
     case 21: launch_cfg_x3<128, 128, 2, 2, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // 8 waves: 64 x 64 x two K-groups
     case 22: launch_cfg_x3<128, 256, 2, 4>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;     // 8 waves of 64 x 64, 256 rows
+    // pre-split activation planes (three bf16 planes written by the producer: no split, no conversion in the loop)
+    case 25: launch_cfg_x3<128, 128, 4, 2, 1, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // tile 5, register staging
+    case 26: launch_cfg_x3<128, 64, 4, 2, 1, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // tile 6
+    case 27: launch_cfg_x3<128, 128, 4, 2, 1, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;  // tile 5, LDS-DMA (three stages)
+    case 28: launch_cfg_x3<128, 64, 4, 2, 1, 2>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;   // tile 6, LDS-DMA
     default: launch_cfg_x3<128, 32, 2, 1>(st, as, epi, npad, n_utt, max_rows, e0, e1); break;
   }
 }
@@ -1273,9 +1357,9 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   }
   // (a segment may read its last padded channels from the NEXT row - a column slice whose width is not a multiple of 32, e.g. the
   //  halves of a 96-channel flow: the packed weights are zero there and the data finite; conv_gemm16_kernel's descriptors do not allow it)
-  if (a.x16)
+  if (a.x16 && a.prec != PREC_F32)
     for (int i = 0; i < a.nseg; ++i)
-      STTS_CHECK(a.prec != PREC_F32 && a.seg[i].ldx % 8 == 0 && a.seg[i].xcol0 % 8 == 0, "conv_gemm: 16-bit activation rows need ldx / xcol0 multiples of 8 (segment %d)", i);
+      STTS_CHECK(a.seg[i].ldx % 8 == 0 && a.seg[i].xcol0 % 8 == 0, "conv_gemm: 16-bit activation rows need ldx / xcol0 multiples of 8 (segment %d)", i);
   // 16-bit activation rows, store epilogue, at least ~one 256 x 256 tile per CU: the persistent LDS-DMA kernel (gemm16.hip.h).
   // force_tile 19 selects it whatever the size (tests), any other forced tile keeps the launch on conv_gemm_f32.
   if (force_tile == 19 || (force_tile == 0 && gemm16_will_run(a, epi, npad, n_utt))) {
@@ -1328,13 +1412,18 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   };
   const long blocks128 = mt * row_tiles(128);
   // split fp32: fp32 call, every segment carries the three bf16 planes of its weight, epilogue with a split instantiation
-  bool x3 = a.prec == PREC_F32 && x3_enabled() && (epi == EPI_STORE || epi == EPI_PRIOR) && !a.x16;
+  bool x3 = a.prec == PREC_F32 && x3_enabled() && (epi == EPI_STORE || epi == EPI_PRIOR);
   for (int i = 0; i < a.nseg; ++i) x3 = x3 && a.seg[i].W16 != nullptr && a.seg[i].w16_plane > 0 && 6 * a.seg[i].w16_plane + 2L * 128 * a.seg[i].ntaps * a.seg[i].kc < (1L << 32);
+  // pre-split activation planes (x16 on an fp32 call): store epilogue, no input affine, no block split-K (the callers know: run_winograd)
+  if (a.x16 && a.prec == PREC_F32) {
+    STTS_CHECK(x3 && epi == EPI_STORE && !a.xaff && !a.sumsq_part, "conv_gemm: pre-split activation planes need the split-fp32 store contraction");
+    for (int i = 0; i < a.nseg; ++i) STTS_CHECK(a.seg[i].x_plane > 0 && a.seg[i].ldx % 8 == 0 && a.seg[i].xcol0 % 8 == 0, "conv_gemm: pre-split activation planes: segment %d misaligned", i);
+  }
   if (force_tile >= 100) {  // tests / tools: 100 + t = tile t on the f32 matrix cores whatever the switch says
     x3 = false;
     force_tile -= 100;
   }
-  if (force_tile != 0 && !((force_tile >= 2 && force_tile <= 6) || force_tile == 8 || (force_tile >= 20 && force_tile <= 22))) x3 = false;  // a forced tile without a split form (LDS-DMA tiles)
+  if (force_tile != 0 && !((force_tile >= 2 && force_tile <= 6) || force_tile == 8 || (force_tile >= 20 && force_tile <= 22) || (a.x16 && force_tile >= 25 && force_tile <= 28))) x3 = false;  // a forced tile without a split form (LDS-DMA tiles)
   int tile = force_tile;
   const bool paired = epi != EPI_STORE && epi != EPI_SPLIT_ACC;  // paired epilogues need 64-column wave tiles
   Plan plan;
@@ -1374,8 +1463,14 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   STTS_CHECK(!((tile == 14 || tile == 15) && (a.prec == PREC_F32 || epi != EPI_STORE)), "conv_gemm: tiles 14 / 15 are for 16-bit operand store launches");
   STTS_CHECK(!((tile >= 16 && tile <= 18) && (a.prec == PREC_F32 || epi != EPI_STORE || !a.x16)), "conv_gemm: tiles 16 - 18 are for 16-bit activation rows, store epilogue");
   STTS_CHECK((tile != 14 && tile != 16) || npad % 256 == 0, "conv_gemm: tiles 14 / 16 need cout padded to 256");
-  STTS_CHECK(!(tile >= 20 && tile <= 22) || x3, "conv_gemm: tiles 20 - 22 exist for the split-fp32 contractions only");
-  const int bn = ((tile >= 14 && tile <= 17) || tile == 22) ? 256 : (tile == 5 || tile == 8 || tile == 11 || tile == 18 || tile == 20 || tile == 21) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
+  STTS_CHECK(!(tile >= 20 && tile <= 28) || x3, "conv_gemm: tiles 20 - 28 exist for the split-fp32 contractions only");
+  if (x3 && a.x16) {  // pre-split activation planes: the 128 x 128 or the 128 x 64 tile, whole launches (no block split-K, no remainder launch)
+    static const int gl_env = getenv("STTS_X3P_GLDS") ? atoi(getenv("STTS_X3P_GLDS")) : 1;  // experiments: 0 = register staging, 1 = LDS-DMA
+    if (tile < 25) tile = (tile == 5 || tile == 8 || tile == 20 || tile == 21 || tile == 22) ? (gl_env ? 27 : 25) : (gl_env ? 28 : 26);
+    plan = Plan();
+  }
+  STTS_CHECK(!(tile >= 25 && tile <= 28) || (x3 && a.x16), "conv_gemm: tiles 25 - 28 read pre-split activation planes");
+  const int bn = ((tile >= 14 && tile <= 17) || tile == 22) ? 256 : (tile == 5 || tile == 8 || tile == 11 || tile == 18 || tile == 20 || tile == 21 || tile == 25 || tile == 27) ? 128 : ((tile == 3 || tile == 4) ? 32 : 64);
   if (plan.full_rt == 0 && plan.rem_rt == 0) plan.full_rt = row_tiles(bn);
   if (tile == 8 || tile == 21) {
     plan.full_rt = row_tiles(bn);
@@ -1390,7 +1485,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // Block-level split-K for launches that cannot fill the chip (phoneme-rate layers, B = 1): one wave's MFMA chain over
   // the whole K (~1 us per 32 channels x taps) is then the critical path, so K is cut over up to 8 blocks per tile.
   int main_ksp = 1;
-  if (splittable && tile != 8 && tile != 21 && plan.rem_rt == 0) {
+  if (splittable && tile != 8 && tile != 21 && tile < 25 && plan.rem_rt == 0) {
     const long blocks = plan.full_rt * mt;
     // (16-bit operands: a contraction that already has one tile per CU is shorter than the reduce pass it would add)
     // K iterations a slice must keep: 4; 8 once the launch has half a chip of blocks anyway (a 16-iteration contraction over 128-256 blocks cut in

@@ -824,7 +824,8 @@ struct WinoScratch {
 };
 inline size_t wino_scratch_floats(const Seg& s, const WinoConv& wc) {
   const long pr = wino_plane_rows(s.rows(), s.n_utt);
-  return (size_t)wc.mats.n * pr * (wc.planes.kc + round_up(wc.planes.N, 32)) + round_up(s.n_utt + 1 + 16, 32) + 32;
+  // (input planes: fp32, or the three bf16 planes of the split form - 6 bytes per element - when the contraction runs as split fp32)
+  return (size_t)wc.mats.n * pr * (wc.planes.kc * 3 / 2 + round_up(wc.planes.N, 32)) + round_up(s.n_utt + 1 + 16, 32) + 32;
 }
 template <int N>
 inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx, const WinoConv& wc, float* Y, int ldy, int act, const float* R, int ldr,
@@ -836,7 +837,14 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   int* segp = reinterpret_cast<int*>(scratch.p);  // [kWinoMaxN + 1] plane offsets j * plane rows: the contraction's "utterances"
   int* goff = segp + 16;                          // [n_utt + 1] first group of every utterance
   float* Xp = scratch.p + round_up(s.n_utt + 1 + 16, 32);
-  float* Mp = Xp + (size_t)n * pr_cap * kc;
+  // split fp32: the input transform writes the three bf16 planes of every component plane (the contraction stages them as they are)
+  // (built, parity-tested, NOT selected: with the planes pre-split the contraction's K loop has no split arithmetic and, on tiles 27 / 28, no register
+  //  staging at all - and runs exactly as fast, 78.1 vs 78.7 us on the decoder's conv2 at B = 8, while this transform writes 1.5 x the bytes and the
+  //  launch loses its remainder-round plan: cfg2 2 037 vs 2 145 utt/s.  STTS_X3_PRESPLIT=1 switches it on for experiments.)
+  static const bool presplit_env = getenv("STTS_X3_PRESPLIT") && atoi(getenv("STTS_X3_PRESPLIT")) != 0;
+  const bool presplit = presplit_env && x3_enabled() && wc.planes.w16_plane > 0 && wc.planes.prec == PREC_F32 && kc % 8 == 0;
+  const long xplane = (long)n * pr_cap * kc;  // elements between two split planes
+  float* Mp = Xp + (size_t)n * pr_cap * kc * 3 / 2;
   WinoIn ti;
   WinoOut to;
   memcpy(ti.Bt, wc.mats.Bt, sizeof(ti.Bt));
@@ -854,8 +862,12 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
     hipLaunchKernelGGL(wino_setup_kernel, dim3(1), dim3(64), 0, st, s.dev, s.n_utt, kWinoMaxN, goff, segp);
     scratch.setup = true;
   }
+  if (presplit)
+    hipLaunchKernelGGL((winograd_input_kernel<N, true>), dim3(ceil_div(groups, 4), ceil_div(kc / 4, 64), s.n_utt), dim3(64, 4), 0, st, X, ldx,
+                       wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff, aff, ld_aff, xplane);
+  else
   hipLaunchKernelGGL((winograd_input_kernel<N>), dim3(ceil_div(groups, 4), ceil_div(kc / 4, 64), s.n_utt), dim3(64, 4), 0, st, X, ldx,
-                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff, aff, ld_aff);
+                     wc.planes.cin_real, s.dev, wc.pad, ti, Xp, kc, goff, aff, ld_aff, 0L);
   std::vector<int> seg_h(n + 1);
   for (int j = 0; j <= n; ++j) seg_h[j] = (int)(j * pr);
   Seg sp{n, seg_h.data(), segp};
@@ -863,6 +875,10 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   GemmArgs a = gemm_args(sp);
   set_seg(a, 0, Xp, kc, 0, wc.planes, 0);
   a.seg[0].w_utt_stride = (long)wc.planes.npad * kc;
+  if (presplit) {
+    a.x16 = 1;
+    a.seg[0].x_plane = xplane;
+  }
   a.N = wc.planes.N; a.bias = nullptr; a.Y = Mp; a.ldy = ldm;
   {
     const int rc = launch_conv_gemm(st, a, EPI_STORE, wc.planes.npad, n, (int)pr);

@@ -177,6 +177,13 @@ extern "C" int stts_bench_gemm(void* stream, int n_utt, int rows_per_utt, int ci
     a.seg[0].X = reinterpret_cast<const float*>(X16);
     a.x16 = 1;
   }
+  if ((tune & 4096) && (tune & 2048)) {  // bit 12: pre-split activation planes (split once, outside the timed launches)
+    STTS_HIP(hipMalloc(&X16, 3 * R * kc * sizeof(unsigned short)));
+    launch_split_rows(st, X, kc, kc, X16, kc, R * kc, R);
+    a.seg[0].X = reinterpret_cast<const float*>(X16);
+    a.seg[0].x_plane = R * kc;
+    a.x16 = 1;
+  }
   long long* dbg = nullptr;
   const size_t dbg_n = 8 * 16384;
   if (tune & 64) { STTS_HIP(hipMalloc(&dbg, dbg_n * 8)); STTS_HIP(hipMemset(dbg, 0, dbg_n * 8)); }

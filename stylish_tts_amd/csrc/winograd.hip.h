@@ -122,10 +122,12 @@ __global__ void __launch_bounds__(64) wino_setup_kernel(const int* __restrict__ 
 }
 
 // grid (ceil(max groups / 4), ceil(C4 / 64), n_utt), block (64, 4): thread = 4 channels of one group
-template <int N>
+// SPLIT: the planes are written as the three bf16 planes of the exact fp32 split (gemm.hip.h, PREC_X3; `xplane` elements apart), so the contraction
+// stages them without a conversion: 6 instead of 4 bytes per element here, no split arithmetic in the contraction's K loop
+template <int N, bool SPLIT = false>
 __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ X, int ldx, int C, const int* __restrict__ seg_off, int pad,
                                                              const WinoIn t, float* __restrict__ Xp, int ldp, const int* __restrict__ goff,
-                                                             const float* __restrict__ aff, int ld_aff) {
+                                                             const float* __restrict__ aff, int ld_aff, long xplane = 0) {
   const int u = blockIdx.z;
   const int lo = seg_off[u], len = seg_off[u + 1] - lo;
   const int groups = (len + kWinoM - 1) / kWinoM;
@@ -165,6 +167,14 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < N; ++q) v += t.Bt[j][q] * d[q];
+    if constexpr (SPLIT) {
+      u32x2 p0, p1, p2;
+      split3_bf16(v, p0, p1, p2);
+      unsigned short* o = reinterpret_cast<unsigned short*>(Xp) + ((long)j * plane_rows + prow) * ldp + c4;
+      *reinterpret_cast<u32x2*>(o) = p0;
+      *reinterpret_cast<u32x2*>(o + xplane) = p1;
+      *reinterpret_cast<u32x2*>(o + 2 * xplane) = p2;
+    } else
     *reinterpret_cast<f32x4*>(Xp + ((long)j * plane_rows + prow) * ldp + c4) = v;
   }
 }

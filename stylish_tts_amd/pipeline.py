@@ -10,9 +10,12 @@ alignment matrix must be sized.  Here nothing is read back in the middle: the fr
 (include/stylish_hip.h, STTS_SEG_CAPACITY) - every buffer and grid is sized by an upper bound of each utterance's frame
 count, the real offsets are computed on the device from the durations (``stts_frame_offsets``) and the waveforms come out
 packed by the real lengths, which the host reads ONCE, with the audio.  The upper bound is frames-per-token x tokens: it
-starts at ``frames_per_token`` (default 8; the reference's table allows 46 per token, real speech averages 5-6), grows to
-1.25 x the largest ratio seen in earlier calls, and a call whose prediction does not fit (the frame counts read with the audio
-exceed a capacity; the truncated segments kept every kernel in bounds) is repeated with exactly the capacities it asked for.
+is ``frames_per_token`` (default 8; the reference's table allows 46 per token, real speech averages 5-6) - a FIXED function of
+the token counts by default, so the same text gets the same buffers, launch plans and bits in every call - and a call whose
+prediction does not fit (the frame counts read with the audio exceed a capacity; the truncated segments kept every kernel in
+bounds) is repeated with exactly the capacities it asked for.  ``adapt=True`` lets the ratio follow the model's predictions
+in steps of 2 frames per token (fewer repeated calls for slow voices; capacities - and through the launch plans the last bits
+of the waveform - can then change between two calls of the same text while the ratio is still settling).
 """
 from __future__ import annotations
 
@@ -31,10 +34,10 @@ class Synthesizer:
 
     MAX_FRAMES_PER_TOKEN = 46  # the largest entry of the reference's duration table (train/utils.py:391-393)
 
-    def __init__(self, engine: HipModel, frames_per_token: float = 8.0, adapt: bool = True):
-        """frames_per_token: capacity (mel frames per token) the frame-rate buffers are sized by; with `adapt` it follows what the model
-        predicts from call to call (adapt=False: the same capacities for the same token counts in every call, hence the same launch
-        plans and bit-identical results from call to call)."""
+    def __init__(self, engine: HipModel, frames_per_token: float = 8.0, adapt: bool = False):
+        """frames_per_token: capacity (mel frames per token) the frame-rate buffers are sized by.  adapt=False (default): the same
+        capacities for the same token counts in every call, hence the same launch plans and bit-identical results from call to call;
+        adapt=True: the ratio follows what the model predicts, quantised to steps of 2 frames per token."""
         self.eng = engine
         self.cfg = engine.cfg
         self._ratio = float(frames_per_token)
@@ -110,11 +113,8 @@ class Synthesizer:
         """One call with events between the stages on the caller's stream: milliseconds of the phoneme-rate part (everything up to
         the frame path's inputs: three text encoders, styles, durations, pitch / energy, length regulator) and of the frame path."""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        self._events = ev
-        try:
-            self._run(token_lists, noise, False, self._lane)
-        finally:
-            self._events = None
+        lane = dict(self._lane, events=ev)  # the events travel with this call only (concurrent map() lanes record nothing into them)
+        self._run(token_lists, noise, False, lane)
         torch.cuda.synchronize(self.eng.device)
         return dict(phoneme_ms=ev[0].elapsed_time(ev[1]), frame_ms=ev[1].elapsed_time(ev[2]))
 
@@ -138,7 +138,7 @@ class Synthesizer:
         toks = torch.tensor([int(v) for t in token_lists for v in t], dtype=torch.int64, device=dev)
         sp = Segments(L, dev)
         main = torch.cuda.current_stream(dev)
-        ev = getattr(self, "_events", None)
+        ev = lane.get("events")
         if ev:
             ev[0].record(main)
         ready = torch.cuda.Event()
@@ -177,17 +177,23 @@ class Synthesizer:
         audio = eng.frame_path(st4, asr, p4, e4, style, noise["prior_noise"], noise["src_noise"], noise["init_phase"], batch_scope=False)
         if ev:
             ev[2].record(main)
-        # the one host read of the call: status + frame counts, together with the audio
-        eng.check_status()
+        # the one host read of the call: the frame counts, together with the audio (the .cpu() waits for the stream)
         T = [int(v) for v in need.cpu().tolist()]
-        if any(t > c for t, c in zip(T, caps)):  # truncated utterances: this call's output is invalid
+        if any(t > c for t, c in zip(T, caps)):  # truncated utterances: this call's output is invalid, and so is whatever the truncated
+            # data left in the error word - it is read (which clears it) and dropped, then the call is repeated with what it asked for
+            try:
+                eng.check_status()
+            except RuntimeError:
+                pass
             e = CapacityOverflow(f"predicted frames {T} exceed the capacities {list(caps)}")
             e.need = T
             raise e
-        # capacity of the next calls: 1.25 x the largest frames-per-token ratio seen so far (monotone, so it settles after the first
-        # calls and equal inputs then get equal capacities, launch plans and results)
+        eng.check_status()  # only a call whose capacities fitted reports the device-side status
+        # adapt: capacity of the next calls = 1.25 x the largest frames-per-token ratio seen so far, rounded UP to a multiple of 2 (monotone
+        # and coarse: it settles after the first calls, and equal inputs then get equal capacities, launch plans and results)
         if self._adapt:
-            self._ratio = min(float(self.MAX_FRAMES_PER_TOKEN), max(self._ratio, 1.25 * max(t / max(n, 1) for t, n in zip(T, L))))
+            want = 1.25 * max(t / max(n, 1) for t, n in zip(T, L))
+            self._ratio = min(float(self.MAX_FRAMES_PER_TOKEN), max(self._ratio, 2.0 * float(np.ceil(want / 2.0))))
         off = np.concatenate([[0], np.cumsum(T)]) * (4 * 75)
         waves = [audio[int(off[i]) : int(off[i + 1])] for i in range(len(L))]
         if return_details:

@@ -129,7 +129,7 @@ def test_synthesizer_repeats_a_call_whose_prediction_overflows(eng):
     w3, _ = tight(toks, noise=noise, return_details=True)
     assert all(torch.equal(a, b) for a, b in zip(w2, w3))
     # adaptive capacity: after one call the next ones fit without a retry, and the capacity ratio has settled
-    syn = Synthesizer(eng, frames_per_token=1.0)
+    syn = Synthesizer(eng, frames_per_token=1.0, adapt=True)
     syn(toks)
     n, r = syn.capacity_retries, syn._ratio
     a1 = syn(toks, noise=noise)

@@ -17,7 +17,7 @@ shapes = [  # name, cin, cout, k
 ]
 B, T4 = int(os.environ.get("B", 8)), int(os.environ.get("T4", 960))
 flt = os.environ.get("SHAPES")
-tiles = [1000 + int(t[1:]) if t.startswith("x") else int(t) for t in os.environ.get("TILES", "2,5,6").split(",")]
+tiles = [1000 + int(t[1:]) if t.startswith("x") else 2000 + int(t[1:]) if t.startswith("p") else int(t) for t in os.environ.get("TILES", "2,5,6").split(",")]
 for name, cin, cout, k in shapes:
     if flt and not any(f in name for f in flt.split(",")):
         continue
@@ -27,10 +27,12 @@ for name, cin, cout, k in shapes:
         nu, rows = (1, 4096) if name.startswith("square") else (B, T4)
         # tile "x5" = tile 5 of the split-fp32 contraction (TUNE bit 11); a plain number = the f32 matrix cores (100 + t: whatever STTS_NO_X3 says)
         tune = int(os.environ.get('TUNE', 0))
-        rc = lib.stts_bench_gemm(None, nu, rows, cin, cout, k, tile if tile < 1000 else tile - 1000, 10, C.byref(ms), tune | (2048 if tile >= 1000 else 0))
+        # "p25" .. "p28": split-fp32 tiles that read PRE-SPLIT activation planes (TUNE bits 11 + 12)
+        t = tile % 1000
+        rc = lib.stts_bench_gemm(None, nu, rows, cin, cout, k, t, 10, C.byref(ms), tune | (2048 if tile >= 1000 else 0) | (4096 if tile >= 2000 else 0))
         if rc != 0:  # this tile does not apply to the shape (e.g. 256-column tiles need cout padded to 256)
             line += f"  tile{tile}:      n/a            "
             continue
         fl = 2.0 * nu * rows * cout * cin * k
-        line += f"  {'x' + str(tile - 1000) if tile >= 1000 else 't' + str(tile)}: {ms.value*1e3:7.1f} us {fl/ms.value/1e9:6.1f} TF"
+        line += f"  {'p' + str(tile - 2000) if tile >= 2000 else 'x' + str(tile - 1000) if tile >= 1000 else 't' + str(tile)}: {ms.value*1e3:7.1f} us {fl/ms.value/1e9:6.1f} TF"
     print(line, flush=True)
