@@ -40,7 +40,11 @@ if ROOT not in sys.path:
 
 SR = 24000
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-MFMA_PEAK_TFLOPS = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": 2500.0, "f16": 2500.0}  # dense 16-bit MFMA (same guide)
+MFMA_PEAK_TFLOPS = {"f32": FP32_MFMA_PEAK_TFLOPS, "f32_native": FP32_MFMA_PEAK_TFLOPS, "bf16": 2500.0, "f16": 2500.0}  # dense 16-bit MFMA (same guide)
+# split-fp32 contractions (csrc/gemm.hip.h PREC_X3): an fp32 product = six bf16 x bf16 products on the bf16 matrix cores, so the
+# speed of light of that form is the dense bf16 peak / 6, in fp32 multiply-add flops
+X3_PRODUCTS = 6
+X3_PEAK_TFLOPS = MFMA_PEAK_TFLOPS["bf16"] / X3_PRODUCTS
 FRAME_MFLOP = 74.1           # frame-rate part, MFLOP per hop-75 frame
 PHONEME_GFLOP_PER_TOKEN = 3.6 / 50.0  # ~3.6 GFLOP per 50-token utterance (text encoders, duration head, pitch/energy)
 CONTRACTION_KERNELS = ("conv_gemm", "wn_fused", "wn_layer", "winograd_", "gemm16")
@@ -204,6 +208,7 @@ def timed_steps(ctx: Ctx, step, steps: int, warmup: int, after_warmup=None) -> f
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    ctx.local_elapsed = time.perf_counter() - t0  # this rank's own time (reported per rank next to the max)
     ctx.barrier()
     return ctx.max_over_ranks(time.perf_counter() - t0)
 
@@ -270,27 +275,42 @@ def run_cfg2(ctx: Ctx, args, traffic, traffic_note):
     audio = torch.empty(B * t4 * 75, dtype=torch.float32, device=ctx.device)
     # global batch = world x B utterances; rank r owns utterances [r B, (r + 1) B): the collector is told that partition
     col = WaveformCollector([75 * t4] * (B * ctx.world), ctx.device, dst=0, parts=[list(range(r * B, (r + 1) * B)) for r in range(ctx.world)]) if ctx.world > 1 else None
+    # N > 1: two audio buffers; step i's waveforms travel to rank 0 on the collector's own stream while step i + 1 computes (a buffer is
+    # written again only after the transfer that read it has completed: its `done` event)
+    bufs = [audio, torch.empty_like(audio)] if col is not None else [audio]
+    done = [None, None]
+    k = [0]
 
     def step():
+        b = k[0] % len(bufs)
+        k[0] += 1
+        if done[b] is not None:
+            torch.cuda.current_stream().wait_event(done[b])
         model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"],
-                         batch_scope=True, out=audio)
+                         batch_scope=True, out=bufs[b])
         if col is not None:
-            col.collect(audio)  # waveforms to rank 0 over xGMI, inside the timed step
+            done[b] = col.collect_async(bufs[b], timed=True)  # waveforms to rank 0 over xGMI, inside the timed region (the final synchronize waits for the last one)
 
     elapsed = timed_steps(ctx, step, args.steps, args.warmup, after_warmup=model.check_status)
-    assert bool(torch.isfinite(audio).all())
+    assert all(bool(torch.isfinite(a).all()) for a in bufs)
+    step_ms_per_rank = ctx.gather_objects(round(1e3 * ctx.local_elapsed / args.steps, 4)) if hasattr(ctx, "local_elapsed") else None
+    collect_ms = col.collect_ms() if col is not None else None
     utts = ctx.world * B * args.steps
     audio_seconds = utts * (t4 * 75 / SR)
-    is_cfg2 = (B, args.mel_frames, args.precision) == (8, 240, "f32")
+    is_cfg2 = (B, args.mel_frames) == (8, 240) and args.precision in ("f32", "f32_native")
     devices = ctx.gather_objects(device_identity(ctx.device))
     out = {
         "metric": "utterances_per_sec", "value": round(utts / elapsed, 3), "unit": "utt/s",
         "rtf": elapsed / audio_seconds, "realtime_x": audio_seconds / elapsed,
         "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32_native" else args.precision, "data": "synthetic",
+        "arithmetic": {"f32": "fp32: every activation and weight is the exact sum of three bf16 terms; the frame-rate contractions of the decoder and the vocoder form each fp32 product from the six "
+                              "largest bf16 x bf16 cross terms on the bf16 matrix cores, fp32 accumulate (nothing is rounded to 16 bits; error against float64 at or below the f32 matrix cores', "
+                              "tests/test_hip_split_fp32.py); the flow, norms, gates, FFTs: fp32 on v_mfma_f32 / VALU.  legs.cfg2_f32_matrix_cores = the same step with v_mfma_f32 only",
+                       "f32_native": "fp32 on the f32 matrix cores (v_mfma_f32_32x32x2_f32) for every contraction"}.get(args.precision, f"{args.precision} matrix-core operands, fp32 accumulate"),
         "config": {
             "workload": ("cfg2: " if is_cfg2 else "side experiment: ") + f"LJSpeech-shaped batch={B} x {args.mel_frames / 80:.1f} s per GPU (T={args.mel_frames} mel frames, {t4 * 75} samples @24 kHz) "
-                        + ("fp32" if args.precision == "f32" else f"{args.precision} matrix-core operands, fp32 accumulate")
+                        + ("fp32" if args.precision in ("f32", "f32_native") else f"{args.precision} matrix-core operands, fp32 accumulate")
                         + ", Decoder + PriorEncoder/reverse flow + freegan iSTFT vocoder (stts_frame_path); no diffusion step exists in the reference",
             "batch_per_gpu": B, "global_batch": B * ctx.world, "frames_per_utt": t4,
             "parallelism": (f"utterance-sharded x{ctx.world}: {ctx.backend} broadcast(weights, once) + exact-size point-to-point collection of the waveforms on rank 0 per step"
@@ -299,6 +319,8 @@ def run_cfg2(ctx: Ctx, args, traffic, traffic_note):
             "distinct_devices": len(set(devices)),
             "frames_per_rank": [B * t4] * ctx.world, "imbalance_max_over_mean": 1.0,
             "collect_bytes_per_step": 0 if ctx.world == 1 else 4 * 75 * t4 * B * (ctx.world - 1),
+            "collect_ms_per_step": None if collect_ms is None else round(collect_ms, 4),  # on the collector's stream, overlapped with the next step's compute
+            "ms_per_step_per_rank": step_ms_per_rank,  # every rank's own wall time over the timed steps (value uses the MAX)
         },
     }
     if not args.pmc_child:
@@ -307,6 +329,32 @@ def run_cfg2(ctx: Ctx, args, traffic, traffic_note):
                                        1e3 * elapsed / args.steps, traffic, traffic_note)
     model.close()
     return out
+
+
+def run_cfg2_native(ctx: Ctx, args):
+    """The bench line's workload with every fp32 contraction on the f32 matrix cores (v_mfma_f32_32x32x2_f32: HipModel(precision="f32_native"), the
+    path of rounds 1-3), same inputs, same step count: what the split-fp32 form of the contractions buys, measured in the same process."""
+    import torch
+
+    from stylish_tts_amd.config import load_model_config
+    from stylish_tts_amd.runtime import HipModel, Segments
+
+    B, t4 = args.batch, 4 * args.mel_frames
+    cfg = load_model_config()
+    w = broadcast_weights(ctx, ["speech_predictor"], cfg)
+    model = HipModel(cfg, ctx.local, precision="f32_native")
+    model.load_weights(w, which=7)
+    seg = Segments([t4] * B, ctx.device)
+    inp = cfg2_inputs(ctx.rank, ctx.device, B, t4)
+    audio = torch.empty(B * t4 * 75, dtype=torch.float32, device=ctx.device)
+
+    def step():
+        model.frame_path(seg, inp["asr"], inp["pitch"], inp["energy"], inp["style"], inp["prior_noise"], inp["src_noise"], inp["init_phase"], batch_scope=True, out=audio)
+
+    elapsed = timed_steps(ctx, step, args.steps, args.warmup, after_warmup=model.check_status)
+    model.close()
+    return {"metric": "utterances_per_sec", "value": round(ctx.world * B * args.steps / elapsed, 3), "unit": "utt/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "dtype": "f32", "arithmetic": "v_mfma_f32_32x32x2_f32 / 16x16x4 for every contraction (no split form)", "steps": args.steps, "warmup": args.warmup}
 
 
 def roofline_leg(ctx: Ctx, args, model, frame_step, ms_per_step, traffic, traffic_note, precision=None):
@@ -344,21 +392,54 @@ def roofline_leg(ctx: Ctx, args, model, frame_step, ms_per_step, traffic, traffi
     c_ms, c_fl, c_ex, c_n = (sum(r[k] for r in con) for k in ("ms", "gflop", "executed_gflop", "launches"))
     all_n, all_ms = sum(r["launches"] for r in recs), sum(r["ms"] for r in recs)
     raw_all = all_ms / psteps
-    scale = min(1.0, plain_ms / raw_all) if raw_all > 0 else 1.0
-    achieved = c_fl / (c_ms * scale) if c_ms > 0 else 0.0  # GFLOP / ms = TFLOP/s
-    executed = c_ex / (c_ms * scale) if c_ms > 0 else 0.0
+    # calibration against the TIMED step (the number `ms_per_step` reports): the instrumented pass serialises the dispatches (an event pair on every
+    # launch, side stream off), so its kernel durations can sum to more than the step they describe; they are scaled down to it, never up
+    scale = min(1.0, ms_per_step / raw_all) if raw_all > 0 else 1.0
+    x3 = [r for r in con if r["kernel"].endswith("_x3")]   # split-fp32 form: bf16 matrix cores
+    nat = [r for r in con if not r["kernel"].endswith("_x3")]
+
+    def fam(rs, pk):
+        ms, fl, ex, n = (sum(r[k] for r in rs) for k in ("ms", "gflop", "executed_gflop", "launches"))
+        ms *= scale
+        return dict(launches_per_step=n // psteps, ms_per_step=round(ms / psteps, 4), algorithmic_tflops=round(fl / ms, 2) if ms else 0.0,
+                    executed_tflops=round(ex / ms, 2) if ms else 0.0, peak=round(pk, 1), frac=round(fl / ms / pk, 4) if ms else 0.0,
+                    frac_executed=round(ex / ms / pk, 4) if ms else 0.0)
+
+    x3_dominant = precision == "f32" and sum(r["ms"] for r in x3) > sum(r["ms"] for r in nat)
+    dom = x3 if x3_dominant else con
+    d_ms, d_fl, d_ex, d_n = (sum(r[k] for r in dom) for k in ("ms", "gflop", "executed_gflop", "launches"))
+    if x3_dominant:
+        peak = X3_PEAK_TFLOPS
+    achieved = d_fl / (d_ms * scale) if d_ms > 0 else 0.0  # GFLOP / ms = TFLOP/s
+    executed = d_ex / (d_ms * scale) if d_ms > 0 else 0.0
     per_rank = ctx.gather_objects(round(c_ms * scale / psteps, 4))
-    return {
-        "kernel": "all Conv1d / Linear contractions of the step (conv_gemm kernels, Winograd-form convs timed with their transforms, fused WaveNet-layer kernels)",
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "achieved_note": "algorithmic (direct-conv) flops / calibrated kernel time: SURVEY.md 8d; a Winograd-form conv is credited with the flops of the direct convolution it replaces",
+    head = {
+        "kernel": ("conv_gemm_f32<..., PREC_X3> - the split-fp32 contraction: every Conv1d / Linear of the decoder and the vocoder (Winograd-form convs timed with their transforms); "
+                   "the flow's fused WaveNet kernel runs on the f32 matrix cores and is listed under f32_mfma_contractions" if x3_dominant else
+                   "all Conv1d / Linear contractions of the step (conv_gemm kernels, Winograd-form convs timed with their transforms, fused WaveNet-layer kernels)"),
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "achieved_note": "algorithmic (direct-conv) fp32 flops / calibrated kernel time: SURVEY.md 8d; a Winograd-form conv is credited with the flops of the direct convolution it replaces",
+        "peak_note": (f"fp32 products formed as {X3_PRODUCTS} bf16 x bf16 products on the bf16 matrix cores (operands split exactly into three bf16 terms, fp32 accumulate): "
+                      f"dense bf16 peak {MFMA_PEAK_TFLOPS['bf16']:.0f} TFLOP/s / {X3_PRODUCTS} = the fp32 multiply-add rate of this form; against the f32 matrix cores' "
+                      f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s the same achieved figure reads {achieved / FP32_MFMA_PEAK_TFLOPS:.3f}") if x3_dominant else f"dense MFMA peak for {precision} operands",
         "executed_tflops": round(executed, 2), "frac_executed": round(executed / peak, 4),
-        "executed_note": "flops the matrix cores actually execute (F(6,7)/F(6,3)/F(2,5)/F(4,5) forms do n/(m r) of the direct multiplies) / the same kernel time",
-        "event_calibration": {"plain_step_gpu_ms": round(plain_ms, 4), "sum_of_event_timed_kernels_ms": round(raw_all, 4), "scale": round(scale, 4),
-                              "frac_uncalibrated": round(c_fl / c_ms / peak, 4) if c_ms > 0 else 0.0,
-                              "note": "durations x scale: the instrumented pass (an event pair on every launch) cannot be shorter than the step it describes"},
+        "executed_note": ("fp32 multiply-add flops whose products the matrix cores actually form (F(6,7)/F(6,3) Winograd forms do n/(m r) of the direct multiplies) / the same kernel time; "
+                          + (f"x {X3_PRODUCTS} = {executed * X3_PRODUCTS:.0f} TFLOP/s of bf16 MFMA work against {MFMA_PEAK_TFLOPS['bf16']:.0f}: the same fraction" if x3_dominant else "F(2,5)/F(4,5) in the flow")),
+    }
+    if x3_dominant:
+        head["f32_mfma_contractions"] = dict(fam(nat, FP32_MFMA_PEAK_TFLOPS), kernels=sorted({r["kernel"] for r in nat}),
+                                             note="contractions still on v_mfma_f32_*: the flow's fused WaveNet kernel (F(2,5) Toom-Cook form) and launches without a split instantiation")
+        head["all_contractions"] = dict(ms_per_step=round(c_ms * scale / psteps, 4), algorithmic_tflops=round(c_fl / (c_ms * scale), 2), executed_tflops=round(c_ex / (c_ms * scale), 2),
+                                        vs_f32_mfma_peak=round(c_fl / (c_ms * scale) / FP32_MFMA_PEAK_TFLOPS, 4))
+    return {
+        **head,
+        "event_calibration": {"timed_step_ms": round(ms_per_step, 4), "plain_step_gpu_ms": round(plain_ms, 4), "sum_of_event_timed_kernels_ms": round(raw_all, 4), "scale": round(scale, 4),
+                              "frac_uncalibrated": round(d_fl / d_ms / peak, 4) if d_ms > 0 else 0.0,
+                              "note": "durations x scale, scale = min(1, timed step / sum of the event-timed kernel durations): the instrumented pass (an event pair on every launch, "
+                                      "no side stream) cannot describe a step longer than the one that was timed; rocprofv3's un-overlapped kernel durations (profiles/) sum to the same "
+                                      "un-scaled figure"},
         "traffic": traffic, "traffic_note": traffic_note,
-        "launches_per_step": c_n // psteps, "avg_launch_ms": round(c_ms * scale / max(c_n, 1), 5),
+        "launches_per_step": d_n // psteps, "avg_launch_ms": round(d_ms * scale / max(d_n, 1), 5),
         "algorithmic_gflop_per_step": round(c_fl / psteps, 2), "executed_gflop_per_step": round(c_ex / psteps, 2),
         "gemm_ms_per_step": round(c_ms * scale / psteps, 4), "gemm_ms_per_step_per_rank": per_rank,
         "gemm_share_of_step": round((c_ms * scale / psteps) / ms_per_step, 4),
@@ -502,7 +583,7 @@ def run_cfg3(ctx: Ctx, args, steps: int, warmup: int):
     w = cfg3_weights(ctx, cfg)
     eng = HipModel(cfg, ctx.local, precision=precision)
     eng.load_weights(w, which=255)
-    syn = Synthesizer(eng)
+    syn = Synthesizer(eng, adapt=True)  # (the synthetic weights predict ~22 frames per token, four times real speech: the capacity ratio settles during the warm-up calls)
     toks = [synth.tokens(f"bench.cfg3.r{ctx.rank}.{i}", 1, P, cfg.text_encoder.tokens)[0].tolist() for i in range(B)]
     waves, det = syn(toks, return_details=True)
     frames = det["frames"]  # mel frames per utterance
@@ -575,15 +656,32 @@ def plumbing_check(args, world, rank):
             ok = all(bool((col.utterance(i) == float(i)).all()) and col.utterance(i).numel() == 3 * frames[i] for i in range(len(frames)))
         t = torch.tensor([1.0 if ok else 0.0])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        cpus = [None] * world
+        dist.all_gather_object(cpus, len(os.sched_getaffinity(0)))  # (pin_rank_cpus ran at rank start)
         if rank == 0:
             rows = [sum(frames[i] for i in p) for p in parts]
             print(json.dumps({"plumbing_check": True, "ok": bool(t.item() == 1.0), "metric": "utterances_per_sec", "value": None, "n_gpus": world,
-                              "ranks": dist.get_world_size(), "backend": "gloo", "frames_per_rank": rows,
+                              "ranks": dist.get_world_size(), "backend": "gloo", "frames_per_rank": rows, "cpus_per_rank": cpus,
                               "imbalance_max_over_mean": round(max(rows) / (sum(rows) / world), 4)}), flush=True)
         if t.item() != 1.0:
             raise SystemExit(4)
     finally:
         dist.destroy_process_group()
+
+
+def pin_rank_cpus(local_rank: int, local_world: int):
+    """A rank's host threads (the launch thread, the two side-stream workers of the full chain, RCCL's proxy thread) stay on that rank's own
+    contiguous slice of the cores this process may use - slice r of `local_world` equal slices, which on a two-socket host also keeps ranks
+    0..N/2-1 on the first socket's cores (the GPUs are enumerated socket by socket).  STTS_NO_AFFINITY=1 leaves the scheduler alone."""
+    if os.environ.get("STTS_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // max(local_world, 1)
+    if per < 2:  # fewer than two cores per rank: pinning would only hurt
+        return None
+    mine = cpus[local_rank * per : (local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -595,14 +693,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step (BASELINE cfg2 = 8; other values are side experiments)")
     ap.add_argument("--mel-frames", type=int, default=240, help="mel frames per utterance (cfg2 = 240 = 3.0 s)")
-    ap.add_argument("--precision", choices=["f32", "bf16", "f16"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "f32_native", "bf16", "f16"], default="f32",
                     help="operand precision of the frame-rate contractions; f32 = BASELINE cfg2 (the bench line); cfg3 / cfg5 default to bf16 / f16")
     ap.add_argument("--cpu-utts", type=int, default=256, help="utterances the CPU baseline times (bounded sample: ~10-30 s of host work)")
     ap.add_argument("--cpu-threads", type=int, default=2, help="BLAS threads per CPU-baseline worker process")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline worker processes (0: fill the one-GPU box's share of 16 cores)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-legs", action="store_true", help="only the bench line (no cfg3 / cfg4 / cfg5 legs)")
-    ap.add_argument("--legs", default="cfg4,cfg5,cfg3", help="comma-separated legs run after the bench line")
+    ap.add_argument("--legs", default="f32mfma,cfg4,cfg5,cfg3", help="comma-separated legs run after the bench line")
     ap.add_argument("--leg-steps", type=int, default=5)
     ap.add_argument("--leg-warmup", type=int, default=2)
     ap.add_argument("--cfg3-batch", type=int, default=64)
@@ -631,6 +729,8 @@ def main():
         sys.exit(rc)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        pin_rank_cpus(int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -684,7 +784,9 @@ def main():
             for leg in [x for x in args.legs.split(",") if x]:
                 t0 = time.perf_counter()
                 try:
-                    if leg in ("cfg4", "cfg5"):
+                    if leg == "f32mfma":
+                        legs["cfg2_f32_matrix_cores"] = run_cfg2_native(ctx, args)
+                    elif leg in ("cfg4", "cfg5"):
                         legs[leg + "_strong"] = run_sharded(ctx, args, leg, args.leg_steps, args.leg_warmup)
                     elif leg == "cfg3":
                         legs["cfg3_full_chain"] = run_cfg3(ctx, args, args.leg_steps, args.leg_warmup)

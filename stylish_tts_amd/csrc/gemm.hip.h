@@ -1522,7 +1522,8 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     if (prof.on) {
       e0 = prof.next();
       e1 = prof.next();
-      prof.add("conv_gemm_f32", 0, flops * (double)ntiles / (double)all_rt, flops * (double)ntiles / (double)all_rt, 0.0);
+      // (bench.py's roofline: "_x3" = the split-fp32 form, six bf16 MFMAs per 16 channels on the bf16 matrix cores; no suffix = the f32 matrix cores)
+      prof.add(x3 ? "conv_gemm_f32_x3" : "conv_gemm_f32", 0, flops * (double)ntiles / (double)all_rt, flops * (double)ntiles / (double)all_rt, 0.0);
     }
     // the kernels live in one translation unit per operand form (csrc/gemm_tu_*.hip, compiled in parallel)
     if (x3) gemm_dispatch_x3(st, as, tile, epi, npad, n_utt, max_rows, e0, e1);

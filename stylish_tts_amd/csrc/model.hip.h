@@ -897,7 +897,7 @@ inline int run_winograd_n(hipStream_t st, const Seg& s, const float* X, int ldx,
   if (timed) {
     prof.on = true;
     (void)hipEventRecord(prof.next(), st);
-    prof.add("winograd_conv", 0, 2.0 * (double)s.rows() * wc.planes.rows_real * wc.planes.cin_real * wc.mats.r,
+    prof.add((x3_enabled() && wc.planes.w16_plane > 0) ? "winograd_conv_x3" : "winograd_conv", 0, 2.0 * (double)s.rows() * wc.planes.rows_real * wc.planes.cin_real * wc.mats.r,
              2.0 * (double)n * (double)pr * wc.planes.rows_real * wc.planes.cin_real, 0.0);
   }
   STTS_HIP(hipGetLastError());

@@ -18,6 +18,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 
 def free_port() -> int:
+    """A port that was free a moment ago (the socket is closed before the ranks bind it: launch_ranks retries with another port when the
+    rendezvous finds it taken)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     p = s.getsockname()[1]
@@ -32,9 +34,33 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
     return env
 
 
-def launch_ranks(script: str, argv: Sequence[str], world: int, timeout: Optional[float] = None, out=None, err=None) -> Tuple[int, List[str]]:
+def launch_ranks(script: str, argv: Sequence[str], world: int, timeout: Optional[float] = None, out=None, err=None, attempts: int = 3) -> Tuple[int, List[str]]:
     """Run `script argv` as `world` rank processes.  Returns (exit status, rank 0's stdout lines).  The status is 0 only if every
-    rank exited 0; when one rank fails the others are terminated (exact PIDs) and the first failing status is returned."""
+    rank exited 0; when one rank fails the others are terminated (exact PIDs) and the first failing status is returned.
+    A run that dies within its first seconds with the rendezvous port taken (EADDRINUSE: somebody bound it between free_port() and the
+    ranks' bind) is started again on another port, up to `attempts` times."""
+    err = err or sys.stderr
+    for k in range(attempts):
+        captured: List[str] = []
+
+        class Tee:
+            def write(self, t):
+                captured.append(t)
+                return err.write(t)
+
+            def flush(self):
+                err.flush()
+
+        t0 = time.monotonic()
+        status, lines = _launch_once(script, argv, world, timeout, out, Tee())
+        in_use = any("EADDRINUSE" in t or "Address already in use" in t or "address already in use" in t for t in captured)
+        if status == 0 or not in_use or lines or time.monotonic() - t0 > 60 or k + 1 == attempts:
+            return status, lines
+        err.write(f"[launcher] rendezvous port was taken: starting the ranks again on another port (attempt {k + 2} of {attempts})\n")
+    return status, lines
+
+
+def _launch_once(script: str, argv: Sequence[str], world: int, timeout: Optional[float], out, err) -> Tuple[int, List[str]]:
     out = out or sys.stdout
     err = err or sys.stderr
     port = free_port()
@@ -55,7 +81,10 @@ def launch_ranks(script: str, argv: Sequence[str], world: int, timeout: Optional
 
     threads = []
     for r in range(world):
-        p = subprocess.Popen([sys.executable, script, *argv], env=rank_env(r, world, port), stdout=subprocess.PIPE, stderr=None)
+        p = subprocess.Popen([sys.executable, script, *argv], env=rank_env(r, world, port), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        te = threading.Thread(target=lambda p=p: [err.write(raw.decode("utf-8", "replace")) for raw in iter(p.stderr.readline, b"")], daemon=True)
+        te.start()
+        threads.append(te)
         procs.append(p)
         t = threading.Thread(target=relay, args=(p, out if r == 0 else err, lines if r == 0 else None, "" if r == 0 else f"[rank {r}] "), daemon=True)
         t.start()

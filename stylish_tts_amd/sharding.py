@@ -37,12 +37,20 @@ def broadcast_state_dict(sd: Optional[Dict[str, np.ndarray]], spec, device, src:
         host = np.concatenate([np.asarray(sd[n], np.float32).reshape(-1) for n, _, _ in spec])
         flat.copy_(torch.from_numpy(host))
     dist.broadcast(flat, src=src)
-    host = flat.cpu().numpy()
+    # ONE device -> host copy into a pinned buffer (the C-ABI's stts_load_weight takes host pointers: weight-norm folding and the Winograd /
+    # Toom-Cook weight transforms run on the host, in double, once per process); the tensors are VIEWS of that buffer, nothing is copied again
+    if flat.device.type == "cuda":
+        pinned = torch.empty(total, dtype=torch.float32).pin_memory()
+        pinned.copy_(flat, non_blocking=True)
+        torch.cuda.current_stream(flat.device).synchronize()
+        host = pinned.numpy()
+    else:
+        host = flat.numpy()
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     off = 0
     for n, s, _ in spec:
         k = int(np.prod(s))
-        out[n] = host[off : off + k].reshape(s).copy()
+        out[n] = host[off : off + k].reshape(s)
         off += k
     return out
 
@@ -119,6 +127,44 @@ class WaveformCollector:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return self.recv
+
+    def collect_async(self, local_audio: torch.Tensor, compute_stream=None, timed: bool = False):
+        """collect() on the collector's OWN stream, behind what `compute_stream` (default: the current stream) has queued so far: the caller's next
+        step computes while this one's waveforms travel.  Returns an event that completes when `local_audio` has been read (the caller waits for it
+        before it overwrites the buffer; with two alternating audio buffers that is two steps later) - None on the CPU, where collect() is synchronous.
+        timed: keep start / stop events of this transfer (collect_ms() averages them)."""
+        if local_audio.device.type != "cuda":
+            self.collect(local_audio)
+            return None
+        dev = local_audio.device
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(device=dev)
+            self._timing = []
+        cs = compute_stream if compute_stream is not None else torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cs)
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(ready)
+            e0 = e1 = None
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self._stream)
+            self.collect(local_audio)
+            local_audio.record_stream(self._stream)
+            if timed:
+                e1.record(self._stream)
+                self._timing.append((e0, e1))
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        return done
+
+    def collect_ms(self) -> Optional[float]:
+        """Mean duration (ms) of the timed collect_async() transfers so far, measured on the collector's stream; None if none was timed."""
+        t = getattr(self, "_timing", None)
+        if not t:
+            return None
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in t) / len(t))
 
     def _collect_via_host(self, flat: torch.Tensor):
         if self.rank == self.dst:

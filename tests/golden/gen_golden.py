@@ -595,8 +595,65 @@ def conv_stft_golden():
     print("  wrote onnx_stft_wiring_evidence.json:", rec["outcome"], rec.get("exception", ""))
 
 
+def atan2_instability_golden(n_trials: int = 16):
+    """Evidence that `har_phase = atan2(Im, Re)` (models/generator.py:405-413) is indeterminate IN THE REFERENCE at the bins the parity tests adopt:
+    the reference's own Generator.forward on frame_path_3s's inputs, once as is and `n_trials` times with the source noise multiplied by
+    (1 + e), e uniform in +-2^-22 (a couple of fp32 ulps: the size of a summation-order change inside torch's own FFT).  Recorded: the bins whose
+    har_phase moves by more than 1 rad in at least one trial (`unstable_idx`), per trial the frames that hold such a bin and the per-frame
+    max-abs difference of the reference's audio against its own unperturbed run, the bins of negligible magnitude (< 2e-4) of the base run, and the
+    bins on the cut whose imaginary part is below 1e-6 of their frame's largest magnitude (`on_cut_idx`: the sign of an imaginary part below the accuracy of a 2048-point fp32 FFT)."""
+    mc = load_model_config_yaml(open(os.path.join(REF_SRC, "stylish_tts/train/config/model.yml")))
+    cfg = load_model_config()
+    sp = load_synth(SpeechPredictor(mc), "speech_predictor", cfg)
+    CutTape.stft = sp.generator.stft
+    T4b = 960
+    asr_b = t(synth.normal("g3.asr", (1, 128, T4b)))
+    pitch_3 = t(synth.pitch_curve("g3.pitch", 1, T4b))
+    energy_3 = t(synth.uniform("g3.energy", (1, T4b)) * 2.0 + 2.0)
+    style_3 = t(synth.normal("g3.style", (1, 64)) * 0.7)
+    nz3 = synth.path_noise("frame960", 1, T4b)
+    with Replay(randn_like=[nz3["prior_noise"]]):
+        xd, _ = sp.decoder(asr_b, pitch_3, energy_3, style_3)
+        z, mean, logstd = sp.prior_encoder(xd)
+        z2, _, _ = sp.flow(z, mean, logstd, 1, style_3.unsqueeze(-1), reverse=True)
+        mel3 = sp.post_flow(z2.mT).mT
+
+    def run(src_noise):
+        with Replay(randn=[src_noise], rand=[nz3["init_phase"]]), CutTape() as cut:
+            pred = sp.generator(mel=mel3, style=style_3, pitch=pitch_3, energy=energy_3)
+        return pred.audio.numpy().reshape(-1), cut.phase[:, :, :-1].contiguous().numpy().reshape(-1), cut.mag[:, :, :-1].contiguous().numpy().reshape(-1)
+
+    audio0, phase0, mag0 = run(nz3["src_noise"])
+    # bins ON the cut within the accuracy of a 2048-point fp32 FFT: the imaginary part |Im| = |X| sin(pi - |har_phase|) is below 1e-6 x the largest |X| of
+    # its frame (an FFT's rounding error is absolute, ~ eps x log2(N) x the size of the frame's spectrum; exact or nearly exact zeros on the
+    # even-symmetric first frame, whose spectrum is real).  The sign of such an imaginary part comes from torch's butterfly order, not from the data: a
+    # perturbation that keeps the frame's symmetry does not flip it, another FFT does
+    frame_max = mag0.reshape(1025, T4b).max(0, keepdims=True)
+    im_abs = mag0.reshape(1025, T4b) * np.sin(np.float64(np.pi) - np.abs(phase0.reshape(1025, T4b)).astype(np.float64))
+    on_cut = np.nonzero(((im_abs < 1e-6 * frame_max) & (np.abs(phase0.reshape(1025, T4b)) > 3.0) & (mag0.reshape(1025, T4b) > 0)).reshape(-1))[0].astype(np.int32)
+    rng = np.random.default_rng(20260405)
+    unstable = np.zeros(phase0.shape, bool)
+    moved_frames = np.zeros((n_trials, T4b), bool)
+    audio_diff = np.zeros((n_trials, T4b), np.float32)
+    moved_count = []
+    for k in range(n_trials):
+        e = rng.uniform(-2.0 ** -22, 2.0 ** -22, nz3["src_noise"].shape).astype(np.float32)
+        a_k, p_k, _ = run((nz3["src_noise"] * (np.float32(1.0) + e)).astype(np.float32))
+        mv = np.abs(p_k.astype(np.float64) - phase0) > 1.0
+        unstable |= mv
+        moved_count.append(int(mv.sum()))
+        moved_frames[k] = mv.reshape(1025, T4b).any(0)
+        audio_diff[k] = np.abs(a_k - audio0).reshape(T4b, 75).max(1)
+        print(f"  trial {k}: {moved_count[-1]} bins moved > 1 rad, audio max-abs diff vs the unperturbed run {audio_diff[k].max():.3e}")
+    save("atan2_instability", unstable_idx=np.nonzero(unstable)[0].astype(np.int32), tiny_idx=np.nonzero(mag0 < 2e-4)[0].astype(np.int32), on_cut_idx=on_cut,
+         moved_frames=np.packbits(moved_frames, axis=1), audio_diff=audio_diff.astype(np.float16), moved_count=np.asarray(moved_count, np.int32),
+         rel_perturbation=np.float32(2.0 ** -22), torch_version=torch.__version__, seed=SEED)
+
+
 if __name__ == "__main__":
-    if "--only-3s-more" in sys.argv:
+    if "--only-atan2" in sys.argv:
+        atan2_instability_golden()
+    elif "--only-3s-more" in sys.argv:
         frame_path_3s_more()
     elif "--only-conv-stft" in sys.argv:
         conv_stft_golden()
@@ -616,3 +673,4 @@ if __name__ == "__main__":
         conv_stft_golden()
         narrow_golden()
         frame_path_3s_more()
+        atan2_instability_golden()

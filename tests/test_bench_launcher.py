@@ -30,6 +30,34 @@ def test_parent_starts_two_ranks_and_relays_one_json_line():
     assert len(out["frames_per_rank"]) == 2 and out["imbalance_max_over_mean"] < 1.1
 
 
+@pytest.mark.timeout(400)
+def test_parent_starts_eight_ranks():
+    """The driver's N = 8 command line on the CPU: eight gloo ranks, one JSON line, every utterance of the fabricated batch collected on rank 0."""
+    r = _run("--gpus", "8", "--plumbing-check")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks"] == 8 and out["ok"] is True and len(out["frames_per_rank"]) == 8
+    assert all(f > 0 for f in out["frames_per_rank"]) and len(out["cpus_per_rank"]) == 8
+
+
+def test_rank_cpu_slices_are_disjoint():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    have = sorted(os.sched_getaffinity(0))
+    got = []
+    try:
+        for r in range(2):
+            got.append(bench.pin_rank_cpus(r, 2))
+            os.sched_setaffinity(0, have)  # (every rank is its own process: each slices the full set)
+    finally:
+        os.sched_setaffinity(0, have)
+    if len(have) >= 4:
+        assert got[0] and got[1] and not set(got[0]) & set(got[1]) and set(got[0]) | set(got[1]) <= set(have)
+
+
 @pytest.mark.timeout(300)
 def test_a_failing_rank_fails_the_parent():
     r = _run("--gpus", "2", "--plumbing-check", "--fail-rank", "1")

@@ -271,3 +271,27 @@ def test_ragged_decoder_on_the_winograd_statistics_path_vs_the_oracle(hip, weigh
         print(f"\n[winograd statistics path] utterance {u} ({t} frames): decoder rel err {err:.2e}")
         assert err < 2e-4, (u, t, err)
         lo += t
+
+
+def test_every_adopted_bin_is_indeterminate_in_the_reference_itself(hip):
+    """The bins at which the HIP path's har_phase is more than 1 rad from the reference's recorded value (= the bins the tests above adopt) all lie in the set
+    the reference itself cannot decide (tests/golden/atan2_instability.npz, tests/test_atan2_instability.py): moved by a two-ulp perturbation of the
+    reference's own input, or an imaginary part below the accuracy of a 2048-point fp32 FFT, or a magnitude below 2e-4."""
+    from stylish_tts_amd import synth
+
+    g, tape = load_golden("atan2_instability"), load_golden("frame_path_3s")
+    T4 = 960
+    s = segs([T4])
+    pitch = synth.pitch_curve("g3.pitch", 1, T4)
+    nz = synth.path_noise("frame960", 1, T4)
+    spec, phase = hip.harmonic_stft(s, dev(pitch[0]), dev(nz["src_noise"].reshape(-1)), dev(nz["init_phase"].reshape(-1)))
+    hip.check_status()
+    ph = phase.cpu().numpy()[:, :1025].T.reshape(-1)  # [bins, T4] flat = the tape's index space
+    idx = tape["cut_idx"].astype(np.int64)
+    dis = idx[np.abs(ph[idx].astype(np.float64) - tape["cut_phase"]) > 1.0]
+    allowed = np.zeros(ph.size, bool)
+    for k in ("unstable_idx", "tiny_idx", "on_cut_idx"):
+        allowed[g[k]] = True
+    stray = dis[~allowed[dis]]
+    print(f"\n[atan2] HIP vs the reference's tape: {dis.size} bins on the other side of the cut ({(dis % T4 == 0).sum()} of them in frame 0), {stray.size} outside the reference's own indeterminate set")
+    assert dis.size > 50 and stray.size == 0, stray[:10]

@@ -9,7 +9,7 @@ from stylish_tts_amd.runtime import HipModel
 cfg = load_model_config()
 w = {m: params.synth_state_dict(params.module_spec(m, cfg), 0, prefix=m + ".") for m in params.MODULE_SPECS}
 eng = HipModel(cfg, 0); eng.load_weights(w, which=255)
-syn = Synthesizer(eng)
+syn = Synthesizer(eng, adapt=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 toks = [synth.tokens(f"fc.{B}.{i}", 1, 14, 178)[0].tolist() for i in range(B)]
 for _ in range(3): syn(toks)

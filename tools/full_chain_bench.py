@@ -9,7 +9,7 @@ from stylish_tts_amd.runtime import HipModel
 cfg = load_model_config()
 w = {m: params.synth_state_dict(params.module_spec(m, cfg), 0, prefix=m + ".") for m in params.MODULE_SPECS}
 eng = HipModel(cfg, 0); eng.load_weights(w, which=255)
-syn = Synthesizer(eng)
+syn = Synthesizer(eng, adapt=True)
 for B, P in ((1, 14), (8, 14), (64, 14), (8, 50)):
     toks = [synth.tokens(f"fc.{B}.{i}", 1, P, 178)[0].tolist() for i in range(B)]
     waves, det = syn(toks, return_details=True)
