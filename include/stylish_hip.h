@@ -90,6 +90,10 @@ int stts_check_status(stts_ctx* ctx, void* stream);
 /* Workspace the frame-rate stages need for `rows` vocoder frames (sum of T4) in `n_utt` utterances,
  * the longest having `max_len` frames. */
 size_t stts_frame_workspace_bytes(const stts_ctx* ctx, int64_t rows, int n_utt, int max_len);
+/* Row stride (floats) of the harmonic spectra `har_spec` / `har_phase` that stts_harmonic_stft writes and stts_vocoder_forward reads: the
+ * n_fft/2 + 1 bins padded to the packed input width of the prior convs (32 in fp32, 64 in the 16-bit operand modes).  Valid after
+ * stts_set_precision; callers size their buffers with it instead of mirroring the padding rule. */
+int stts_har_ld(const stts_ctx* ctx);
 
 /* Decoder.forward (models/decoder.py:47-60) incl. every AdaptiveDecoderBlock (models/ada_norm.py:166-182).
  * asr [rows, ld_asr>=128], pitch/energy [rows] (already at the hop/4 rate), style [n_utt, 64] -> x [rows, 512]. */

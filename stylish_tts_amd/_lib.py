@@ -60,6 +60,7 @@ SIGNATURES = {
     "stts_finalize_weights": (_I, [_P, _I]),
     "stts_check_status": (_I, [_P, _P]),
     "stts_frame_workspace_bytes": (_SZ, [_P, _I64, _I, _I]),
+    "stts_har_ld": (_I, [_P]),
     "stts_decoder_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ]),
     "stts_prior_flow_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _SZ]),
     "stts_harmonic_stft": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _SZ]),

@@ -120,13 +120,24 @@ int stts_check_status(stts_ctx* c, void* stream) {
   STTS_HIP(hipStreamSynchronize((hipStream_t)stream));
   STTS_HIP(hipMemcpy(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (e) {
+    // bit flags (the kernels set them with atomicOr): every pending condition is reported, the most specific text first
     STTS_HIP(hipMemset(c->d_err, 0, sizeof(int)));
-    if (e == 2) return stts::fail("text encoder: token id outside [0, tokens)");
-    if (e == 4) return stts::fail("harmonic source: an utterance is too short for the STFT's reflect padding (needs more than %d samples)", kNfft / 2);
-    return stts::fail("harmonic source: a frame is voiced (f0 > 10 Hz) but no f0 exceeds 20 Hz (reference raises: models/generator.py:285)");
+    std::string msg;
+    if (e & 2) msg += "text encoder: token id outside [0, tokens); ";
+    if (e & 4) msg += "harmonic source: an utterance is too short for the STFT's reflect padding (needs more than " + std::to_string(kNfft / 2) + " samples); ";
+    if (e & 1) msg += "harmonic source: a frame is voiced (f0 > 10 Hz) but no f0 exceeds 20 Hz (reference raises: models/generator.py:285); ";
+    if (e & ~7) msg += "unknown device error bits " + std::to_string(e & ~7) + "; ";
+    msg.resize(msg.size() - 2);
+    return stts::fail("%s", msg.c_str());
   }
   return 0;
   API_END
+}
+
+int stts_har_ld(const stts_ctx* c) {
+  if (!c) return 0;
+  if (c->amp_prior.kc) return har_ld(c);  // the generator is packed: the prior convs' input width
+  return round_up(kBins, c->prec != PREC_F32 ? 64 : 32);  // before: what finalize_frame will pad the bins to in this precision (kc_align)
 }
 
 size_t stts_frame_workspace_bytes(const stts_ctx* c, int64_t rows, int n_utt, int max_len) { return frame_workspace_bytes(c, rows, n_utt, max_len); }

@@ -19,6 +19,7 @@
 #include "wn_fused.hip.h"
 #include "wn_fused16.hip.h"
 #include "wn_block16.hip.h"
+#include "wn_fused_x3.hip.h"
 #include "winograd.hip.h"
 
 namespace stts {
@@ -96,8 +97,15 @@ struct WnFusedW {
   unsigned short* H2b[4] = {};  // res_skip in wn_block16_kernel's tile order (wave w: res 32w.., skip 32w..; layer 3: skip only)
   unsigned short* H3 = nullptr;
   unsigned short* H4 = nullptr;
+  // split fp32 (wn_fused_x3_kernel): the 16-bit kernels' fragment arrays as the three bf16 planes of the exact split, direct (tap-major) conv
+  unsigned short* X1[4] = {};
+  unsigned short* X2[4] = {};
+  unsigned short* X3 = nullptr;
+  unsigned short* X4 = nullptr;
+  long xp1 = 0, xp2[4] = {}, xp3 = 0, xp4 = 0;  // f32x4 units between two planes
   bool ready = false;    // fp32 fragments packed
   bool ready16 = false;  // 16-bit fragments packed
+  bool ready_x3 = false; // split-fp32 fragments packed
 };
 
 struct FlowLayerW {
@@ -460,6 +468,18 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
       }, f32_to_bf16, f32_to_f16);
       STTS_TRY(dev_upload(c, f16v, &o->H1[i]));
     }
+    const bool x3pack = c->prec == PREC_F32 && c->allow_x3 && c->pack_x3 && x3_enabled();
+    if (x3pack) {
+      std::vector<std::vector<float>> kr((size_t)2 * C, std::vector<float>(5 * C));
+      for (int n = 0; n < 2 * C; ++n)
+        for (int ci = 0; ci < C; ++ci)
+          for (int k = 0; k < 5; ++k) kr[n][(size_t)k * C + ci] = w.data[((size_t)n * C + ci) * 5 + k];
+      const std::vector<unsigned short> fx = pack_fragments_x3(kWnWaves, 5 * C / 32, 4, [&](int wv, int t, int col) {
+        return kr[(size_t)(t >> 1) * C + 32 * wv + 16 * (t & 1) + col].data();
+      }, split3_host);
+      STTS_TRY(dev_upload(c, fx, &o->X1[i]));
+      o->xp1 = (long)(fx.size() / 3 / 8);
+    }
     for (int v = 0; v < 3 && c->prec == PREC_F32; ++v) {
       WnFusedMats mt;
       const int vm = v == 0 ? 2 : (v == 1 ? 4 : 1);
@@ -489,6 +509,13 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
     if (c->prec == PREC_F32) {
       const std::vector<float> f2 = pack_fragments(kWnWaves, C / 16, nct, [&](int wv, int t, int col) { return rr[(size_t)16 * nct * wv + 16 * t + col].data(); });
       STTS_TRY(dev_upload(c, f2, &o->W2[i]));
+      if (x3pack) {
+        const std::vector<unsigned short> fx = pack_fragments_x3(kWnWaves, C / 32, nct, [&](int wv, int t, int col) {
+          return wr.data.data() + ((size_t)16 * nct * wv + 16 * t + col) * C;
+        }, split3_host);
+        STTS_TRY(dev_upload(c, fx, &o->X2[i]));
+        o->xp2[i] = (long)(fx.size() / 3 / 8);
+      }
     } else {
       const std::vector<unsigned short> f2 = pack_fragments16(c->prec, kWnWaves, C / 32, nct, [&](int wv, int t, int col) {
         return wr.data.data() + ((size_t)16 * nct * wv + 16 * t + col) * C;
@@ -509,6 +536,13 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
   if (c->prec == PREC_F32) {
     const std::vector<float> f3 = pack_fragments(kWnWaves, C / 16, 2, [&](int wv, int t, int col) { return (t == 0 ? rm : rl)[(size_t)16 * wv + col].data(); });
     STTS_TRY(dev_upload(c, f3, &o->W3));
+    if (c->allow_x3 && c->pack_x3 && x3_enabled()) {
+      const std::vector<unsigned short> fx = pack_fragments_x3(kWnWaves, C / 32, 2, [&](int wv, int t, int col) {
+        return (t == 0 ? pm : pl).data.data() + ((size_t)16 * wv + col) * C;
+      }, split3_host);
+      STTS_TRY(dev_upload(c, fx, &o->X3));
+      o->xp3 = (long)(fx.size() / 3 / 8);
+    }
   } else {
     const std::vector<unsigned short> f3 = pack_fragments16(c->prec, kWnWaves, C / 32, 2, [&](int wv, int t, int col) {
       return (t == 0 ? pm : pl).data.data() + ((size_t)16 * wv + col) * C;
@@ -525,6 +559,13 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
   if (c->prec == PREC_F32) {
     const std::vector<float> f4 = pack_fragments(kWnWaves, C / 32, 2, [&](int wv, int t, int col) { return rp[(size_t)32 * wv + 16 * t + col].data(); });
     STTS_TRY(dev_upload(c, f4, &o->W4));
+    if (c->allow_x3 && c->pack_x3 && x3_enabled()) {
+      const std::vector<unsigned short> fx = pack_fragments_x3(kWnWaves, C / 64, 2, [&](int wv, int t, int col) {
+        return wp.data.data() + ((size_t)32 * wv + 16 * t + col) * (C / 2);
+      }, split3_host);
+      STTS_TRY(dev_upload(c, fx, &o->X4));
+      o->xp4 = (long)(fx.size() / 3 / 8);
+    }
   } else {
     const std::vector<unsigned short> f4 = pack_fragments16(c->prec, kWnWaves, C / 64, 2, [&](int wv, int t, int col) {
       return wp.data.data() + ((size_t)32 * wv + 16 * t + col) * (C / 2);
@@ -534,6 +575,7 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
   STTS_TRY(dev_upload(c, bp->data, &o->b4));
   o->ready = c->prec == PREC_F32;
   o->ready16 = c->prec != PREC_F32;
+  o->ready_x3 = c->prec == PREC_F32 && c->allow_x3 && c->pack_x3 && x3_enabled();
   return 0;
 }
 
@@ -1396,6 +1438,18 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     if (force == 4 || force == 8 || force == 16) fused16_rt = force;
     if (force == -1) fused16_rt = 0;  // the staged kernel
   }
+  // split fp32 (fp32 mode): wn_fused_x3_kernel on 32-row blocks, 64-row blocks once those fill the chip more than once (the taller block halves the
+  // weight stream per row); small batches (16-row blocks win there) stay on the f32 kernel's direct form
+  int fusedx3_rt = 0;
+  if (c->prec == PREC_F32 && fused_m != 0 && fused_m != 1 && c->flow[0].fused.ready_x3) {
+    long b64 = 0;
+    for (int u = 0; u < s.n_utt; ++u) b64 += ceil_div(s.host[u + 1] - s.host[u], 64);
+    fusedx3_rt = b64 > 256 ? 4 : 2;
+    const int force = getenv("STTS_WN_X3") ? atoi(getenv("STTS_WN_X3")) : 0;  // tests / tools: 2 / 4 = block shape, -1 = the f32 kernel
+    if (force == 2 || force == 4) fusedx3_rt = force;
+    if (force == -1) fusedx3_rt = 0;
+  }
+  if (c->prec == PREC_F32 && fused_m == 1 && c->flow[0].fused.ready_x3 && getenv("STTS_WN_X3") && atoi(getenv("STTS_WN_X3")) > 0) fusedx3_rt = atoi(getenv("STTS_WN_X3")) == 4 ? 4 : 2;
   auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
   float* blk_in = hf;  // wn_block16_kernel: the coupling layer's h_0 (ping-pongs between hf and hf2)
   for (int f = 7; f >= 0; --f) {
@@ -1497,11 +1551,34 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         e1 = prof.next();
         const double rest = 2.0 * (double)R * (double)L.rs[i].N * fh + extra, conv = 2.0 * (double)R * 2 * fh * 5 * fh;
         // the fused kernel executes F(M,5): M + 4 instead of 5 M products per channel and group of M rows
-        prof.add(fused_m ? "wn_fused_kernel" : (fused16_rt ? "wn_fused16_kernel" : "wn_layer_kernel"), 0, conv + rest,
-                 (fused_m ? conv * (fused_m + 4) / (5.0 * fused_m) : conv) + rest, 0.0);
+        prof.add(fusedx3_rt ? "wn_fused_kernel_x3" : fused_m ? "wn_fused_kernel" : (fused16_rt ? "wn_fused16_kernel" : "wn_layer_kernel"), 0, conv + rest,
+                 ((fused_m && !fusedx3_rt) ? conv * (fused_m + 4) / (5.0 * fused_m) : conv) + rest, 0.0);
       }
       const dim3 wgrid(ceil_div(ml, 32), s.n_utt);
-      if (fused_m) {
+      if (fusedx3_rt) {
+        WnFusedX3Args xa;
+        memset(&xa, 0, sizeof(xa));
+        WnFused16Args& fa = xa.b;
+        fa.Hin = hcur; fa.Hout = w.Hout; fa.Out = outf; fa.seg_off = s.dev;
+        fa.W1 = L.fused.X1[i]; fa.b1 = L.fused.b1[i]; fa.W2 = L.fused.X2[i]; fa.b2 = L.fused.b2[i];
+        xa.p1 = L.fused.xp1; xa.p2 = L.fused.xp2[i]; xa.p3 = L.fused.xp3;
+        fa.gate = cond; fa.ld_gate = w.ld_gate; fa.gcol0 = w.gcol0; fa.out_acc = w.out_acc; fa.tail = w.tail;
+        fa.W3 = L.fused.X3; fa.b3m = L.fused.b3m; fa.b3s = L.fused.b3s; fa.Z = w.Z; fa.ldz = w.ldz; fa.zcol0 = w.zcol0;
+        if (w.tail > 1) { fa.W4 = c->flow[f - 1].fused.X4; xa.p4 = c->flow[f - 1].fused.xp4; fa.b4 = c->flow[f - 1].fused.b4; fa.Hpre = w.Hpre; }
+        if (s.n_utt <= kWnSegInline && !s.cap) {
+          fa.n_inline = s.n_utt;
+          memcpy(fa.seg_inline, s.host, (s.n_utt + 1) * sizeof(int));
+        }
+        const dim3 fgrid(ceil_div(ml, 16 * fusedx3_rt), s.n_utt);
+        if (fusedx3_rt == 4) {
+          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
+          else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
+        } else {
+          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<2, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
+          else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<2, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
+        }
+      }
+      else if (fused_m) {
         auto launch = [&](auto mtag) {
           constexpr int M = decltype(mtag)::value;
           WnFusedArgs<M> fa;

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const long* __restrict__ tok
     const int r = (int)(i / nv), c4 = (int)(i % nv) * 4;
     long t = tokens[r];
     if (t < 0 || t >= n_tokens_vocab) {
-      atomicExch(err, 2);
+      atomicOr(err, 2);
       t = 0;
     }
     const float4 e = *reinterpret_cast<const float4*>(emb + t * C + c4);

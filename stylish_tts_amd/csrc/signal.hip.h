@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0,
   const int lo = seg_off[u], nfr = seg_off[u + 1] - lo;
   // the STFT reflects kNfft / 2 samples at both ends: shorter utterances cannot be padded (torch.stft raises; the host checks this
   // when it knows the lengths, here for lengths that only exist on the device)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (long)nfr * kHop <= kNfft / 2) atomicMax(err, 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (long)nfr * kHop <= kNfft / 2) atomicOr(err, 4);  // (bit flags: several conditions can be pending at once, stts_check_status reports each)
   float mnf = stats[2 * u];
   int anyv = stats[2 * u + 1] > 0.5f;
   if (batch_scope) {  // minimum / any over the call's utterances: lanes take utterances, one wave reduction (every thread looping over all of them was half of this kernel at B = 64)
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) pcph_kernel(const float* __restrict__ f0,
   int K = 0;
   if (anyv) {
     if (isinf(mnf)) {
-      if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(err, 1);
+      if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, 1);
       K = 16;
     } else {
       K = min(16, (int)(12000.0 / (double)mnf));

@@ -91,8 +91,8 @@ class HipModel:
         self.ctx = h
         self.precision = precision
         _lib.check(self.lib.stts_set_precision(self.ctx, self.PRECISIONS[precision]))
-        # row stride of the harmonic spectra = the prior convs' packed input width: 1025 bins padded to 32 (fp32) or 64 (16-bit modes)
-        self.har_ld = N_BINS_LD if precision in ("f32", "f32_native") else 1088
+        # row stride of the harmonic spectra = the prior convs' packed input width, asked from the library (1025 bins padded to 32 in fp32, 64 in the 16-bit modes)
+        self.har_ld = int(self.lib.stts_har_ld(self.ctx))
         # grow-only workspaces, one per launch stream (stages issued on different streams may run concurrently)
         self._ws: Dict[int, torch.Tensor] = {}
         self._pws: Dict[int, torch.Tensor] = {}
