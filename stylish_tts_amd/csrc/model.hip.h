@@ -20,6 +20,7 @@
 #include "wn_fused16.hip.h"
 #include "wn_block16.hip.h"
 #include "wn_fused_x3.hip.h"
+#include "wn_block_x3.hip.h"
 #include "winograd.hip.h"
 
 namespace stts {
@@ -100,6 +101,7 @@ struct WnFusedW {
   // split fp32 (wn_fused_x3_kernel): the 16-bit kernels' fragment arrays as the three bf16 planes of the exact split, direct (tap-major) conv
   unsigned short* X1[4] = {};
   unsigned short* X2[4] = {};
+  unsigned short* X2b[4] = {};  // res_skip in wn_block_x3_kernel's tile order (as H2b)
   unsigned short* X3 = nullptr;
   unsigned short* X4 = nullptr;
   long xp1 = 0, xp2[4] = {}, xp3 = 0, xp4 = 0;  // f32x4 units between two planes
@@ -515,6 +517,13 @@ inline int pack_wn_fused(stts_ctx* c, const std::string& q, const HostTensor& pm
         }, split3_host);
         STTS_TRY(dev_upload(c, fx, &o->X2[i]));
         o->xp2[i] = (long)(fx.size() / 3 / 8);
+        // wn_block_x3_kernel: wave w owns the res rows AND the skip rows [32 w, 32 w + 32) (tiles: res, res + 16, skip, skip + 16; layer 3: skip, skip + 16)
+        const int nctb = n_rs == 2 * C ? 4 : 2;
+        const std::vector<unsigned short> fxb = pack_fragments_x3(kWnWaves, C / 32, nctb, [&](int wv, int t, int col) {
+          const int row = n_rs == 2 * C ? (t < 2 ? 32 * wv + 16 * t + col : C + 32 * wv + 16 * (t - 2) + col) : 32 * wv + 16 * t + col;
+          return wr.data.data() + (size_t)row * C;
+        }, split3_host);
+        STTS_TRY(dev_upload(c, fxb, &o->X2b[i]));  // (same size as X2[i]: xp2[i] is its plane stride too)
       }
     } else {
       const std::vector<unsigned short> f2 = pack_fragments16(c->prec, kWnWaves, C / 32, nct, [&](int wv, int t, int col) {
@@ -1450,6 +1459,20 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     if (force == -1) fusedx3_rt = 0;
   }
   if (c->prec == PREC_F32 && fused_m == 1 && c->flow[0].fused.ready_x3 && getenv("STTS_WN_X3") && atoi(getenv("STTS_WN_X3")) > 0) fusedx3_rt = atoi(getenv("STTS_WN_X3")) == 4 ? 4 : 2;
+  // ... and one launch per COUPLING layer (wn_block_x3_kernel: four WaveNet layers + post + coupling + next pre, h and `out` on chip) with 32 output
+  // rows per block (48 computed), 48 (64 computed: what fits the LDS next to the fp32 residual stream) once the 32-row blocks exceed one chip round
+  int blockx3_rt = 0;
+  if (fusedx3_rt) {
+    long b32 = 0;
+    for (int u = 0; u < s.n_utt; ++u) b32 += ceil_div(s.host[u + 1] - s.host[u], 32);
+    (void)b32;
+    // (built, parity-tested, NOT selected: 8 launches of 98 us against 32 of 22.6 at B = 8 - 0.79 vs 0.72 ms per step - and 1.80 vs 1.30 ms at B = 16: the
+    //  2 x 8 halo rows are 1.5 x the matrix work of a 32-row block and the four layers of a block run back to back on one wave per SIMD, which costs
+    //  more than the 24 launch ramps + prologues it saves.  STTS_WN_X3B=3 | 4 selects it for experiments.)
+    const int force = getenv("STTS_WN_X3B") ? atoi(getenv("STTS_WN_X3B")) : 0;  // tests / tools: 3 / 4 = tile shape
+    if (force == 3 || force == 4) blockx3_rt = force;
+    if (force == -1) blockx3_rt = 0;
+  }
   auto wptr = [&](const PackedConv& pc) -> const void* { return c->prec != PREC_F32 ? (const void*)pc.W16 : (const void*)pc.W; };
   float* blk_in = hf;  // wn_block16_kernel: the coupling layer's h_0 (ping-pongs between hf and hf2)
   for (int f = 7; f >= 0; --f) {
@@ -1487,6 +1510,42 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
       set_seg(a, 0, z, fh, p * half, L.pre);
       a.N = fh; a.bias = L.pre.bias; a.Y = hf; a.ldy = fh;
       STTS_TRY(launch_conv_gemm(st, a, EPI_STORE, L.pre.npad, s.n_utt, ml));
+    }
+    if (blockx3_rt) {
+      // ---- split fp32: one launch for the whole coupling layer; reads h_0 = pre(z0) from `blk_in`, writes the next coupling layer's h_0 to the other buffer
+      WnBlockX3Args ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.Hin = blk_in; ba.seg_off = s.dev; ba.gate = cond; ba.ld_gate = c->flow_style.ld();
+      double flops = 0;
+      for (int i = 0; i < 4; ++i) {
+        ba.W1[i] = L.fused.X1[i]; ba.b1[i] = L.fused.b1[i]; ba.W2[i] = L.fused.X2b[i]; ba.b2[i] = L.fused.b2[i]; ba.p2[i] = L.fused.xp2[i];
+        ba.gcol0[i] = L.cond_col0 + i * 2 * fh;
+        flops += 2.0 * (double)R * 2 * fh * 5 * fh + 2.0 * (double)R * (double)L.rs[i].N * fh;
+      }
+      ba.p1 = L.fused.xp1; ba.p3 = L.fused.xp3;
+      ba.tail = f > 0 ? 2 : 1;
+      ba.W3 = L.fused.X3; ba.b3m = L.fused.b3m; ba.b3s = L.fused.b3s; ba.Z = z; ba.ldz = fh; ba.zcol0 = (1 - p) * half;
+      flops += 2.0 * (double)R * fh * fh;
+      float* blk_out = blk_in == hf ? hf2 : hf;
+      if (f > 0) {
+        ba.W4 = c->flow[f - 1].fused.X4; ba.p4 = c->flow[f - 1].fused.xp4; ba.b4 = c->flow[f - 1].fused.b4; ba.Hpre = blk_out;
+        flops += 2.0 * (double)R * fh * half;
+      }
+      GemmProfiler& prof = gemm_profiler();
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (prof.on) {
+        e0 = prof.next();
+        e1 = prof.next();
+        // executed = the algorithmic flops x the halo recompute (16 RT computed rows per 16 RT - 16 output rows)
+        prof.add("wn_block_kernel_x3", 0, flops, flops * (16.0 * blockx3_rt) / (16.0 * blockx3_rt - 16.0), 0.0);
+      }
+      const int out_rows = 16 * blockx3_rt - 2 * kWnBlockX3Halo;
+      const dim3 bgrid(ceil_div(ml, out_rows), s.n_utt);
+      if (blockx3_rt == 3) STTS_LAUNCH_TIMED((wn_block_x3_kernel<3>), bgrid, dim3(64 * kWnWaves), st, e0, e1, ba);
+      else STTS_LAUNCH_TIMED((wn_block_x3_kernel<4>), bgrid, dim3(64 * kWnWaves), st, e0, e1, ba);
+      blk_in = blk_out;
+      STTS_HIP(hipGetLastError());
+      continue;
     }
     if (fused16_rt == 16) {
       // ---- one launch for the whole coupling layer (16-bit modes, large batches): reads h_0 = pre(z0) from `blk_in`, writes the next

@@ -116,15 +116,23 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[h][c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the B fragments of a step (RT row tiles x three planes of the conv tile at one tap / k-step) are fetched from LDS one step AHEAD of the
+  // 6 x 4 x RT MFMAs that consume them: the wave is alone on its SIMD, nothing else hides an LDS round trip
+  f32x4 avc[RT][3];
+  auto frags = [&](f32x4(&dst)[RT][3], int step) {  // step = 2 half + tt = 4 tap + k-step
+    const int tap = step >> 2, t = step & 3;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[rt][p] = rows_frag(Hs + p * HPL, 16 * rt + l15 + tap, t);
+  };
+  frags(avc, 0);
   auto half1 = [&](int half, const f32x4(&cur)[3][H1]) {
-    const int tap = half >> 1, t0 = (half & 1) * 2;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-      f32x4 av[RT][3];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) av[rt][p] = rows_frag(Hs + p * HPL, 16 * rt + l15 + tap, t0 + tt);
+      const int step = 2 * half + tt;
+      f32x4 avn[RT][3];
+      frags(avn, min(step + 1, 4 * TAPS - 1));  // (the last step re-reads itself: no branch in the loop body)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -132,8 +140,12 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const int j = (tt * 2 + h) * CT + c;
-            acc[h][c][rt] = mma6(cur[0][j], cur[1][j], cur[2][j], av[rt], acc[h][c][rt]);
+            acc[h][c][rt] = mma6(cur[0][j], cur[1][j], cur[2][j], avc[rt], acc[h][c][rt]);
           }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) avc[rt][p] = avn[rt][p];
     }
   };
 #pragma unroll 1

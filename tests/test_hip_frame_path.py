@@ -134,18 +134,20 @@ def test_prior_flow_golden(hip):
     close(cm(mel, 1, 512, 64), g["mel"], what="post_flow")
 
 
-@pytest.mark.parametrize("m", ["1", "2", "4", "16", "x2", "x4"])
+@pytest.mark.parametrize("m", ["1", "2", "4", "16", "x2", "x4", "b3", "b4"])
 def test_prior_flow_fused_wavenet_kernel(hip, weights, m, monkeypatch):
     """wn_fused_kernel (direct form with 16-row blocks / F(2,5) with 32-row blocks / F(4,5) with 64-row blocks; picked by batch
     size in production; "16" = the staged 16-row kernel it replaced for the smallest batches) and wn_fused_x3_kernel (the split-fp32
-    form, "x2" / "x4" = 32- / 64-row blocks: what production runs from ~B = 5 on) forced
+    form, "x2" / "x4" = 32- / 64-row blocks, one launch per WaveNet layer: what production runs from ~B = 5 on; "b3" / "b4" = wn_block_x3_kernel, one launch per coupling layer with 32 / 48
+    output rows per block: built and measured, not selected) forced
     on small and ragged inputs: the reference golden, and per-utterance oracle runs for lengths that leave partial
     blocks, one-row tails and utterances shorter than the conv's reach."""
     from oracle import stylish_oracle as O
     from stylish_tts_amd import synth
 
-    monkeypatch.setenv("STTS_WN_M", "2" if m.startswith("x") else m)
-    monkeypatch.setenv("STTS_WN_X3", m[1:] if m.startswith("x") else "-1")
+    monkeypatch.setenv("STTS_WN_M", "2" if m[0] in "xb" else m)
+    monkeypatch.setenv("STTS_WN_X3", m[1:] if m.startswith("x") else ("2" if m.startswith("b") else "-1"))
+    monkeypatch.setenv("STTS_WN_X3B", m[1:] if m.startswith("b") else "0")
     g = load_golden("flow")
     nz = synth.path_noise("frame64", 1, 64)
     mel, zp, zf = hip.prior_flow(segs([64]), tm(g["x"]), dev(g["style"]), tm(nz["prior_noise"]), return_z=True)
