@@ -414,8 +414,9 @@ def roofline_leg(ctx: Ctx, args, model, frame_step, ms_per_step, traffic, traffi
     executed = d_ex / (d_ms * scale) if d_ms > 0 else 0.0
     per_rank = ctx.gather_objects(round(c_ms * scale / psteps, 4))
     head = {
-        "kernel": ("conv_gemm_f32<..., PREC_X3> - the split-fp32 contraction: every Conv1d / Linear of the decoder and the vocoder (Winograd-form convs timed with their transforms); "
-                   "the flow's fused WaveNet kernel runs on the f32 matrix cores and is listed under f32_mfma_contractions" if x3_dominant else
+        "kernel": ("the split-fp32 contractions: conv_gemm_f32<..., PREC_X3> (every Conv1d / Linear of the decoder and the vocoder; Winograd-form convs timed with their "
+                   "transforms) and wn_fused_x3_kernel (the flow's fused WaveNet layers)" + ("; contractions still on the f32 matrix cores are listed under f32_mfma_contractions" if nat else "")
+                   if x3_dominant else
                    "all Conv1d / Linear contractions of the step (conv_gemm kernels, Winograd-form convs timed with their transforms, fused WaveNet-layer kernels)"),
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
         "achieved_note": "algorithmic (direct-conv) fp32 flops / calibrated kernel time: SURVEY.md 8d; a Winograd-form conv is credited with the flops of the direct convolution it replaces",
@@ -427,8 +428,9 @@ def roofline_leg(ctx: Ctx, args, model, frame_step, ms_per_step, traffic, traffi
                           + (f"x {X3_PRODUCTS} = {executed * X3_PRODUCTS:.0f} TFLOP/s of bf16 MFMA work against {MFMA_PEAK_TFLOPS['bf16']:.0f}: the same fraction" if x3_dominant else "F(2,5)/F(4,5) in the flow")),
     }
     if x3_dominant:
-        head["f32_mfma_contractions"] = dict(fam(nat, FP32_MFMA_PEAK_TFLOPS), kernels=sorted({r["kernel"] for r in nat}),
-                                             note="contractions still on v_mfma_f32_*: the flow's fused WaveNet kernel (F(2,5) Toom-Cook form) and launches without a split instantiation")
+        if nat:
+            head["f32_mfma_contractions"] = dict(fam(nat, FP32_MFMA_PEAK_TFLOPS), kernels=sorted({r["kernel"] for r in nat}),
+                                                 note="contractions on v_mfma_f32_*: launches without a split instantiation (small batches: the flow's 16-row F(1,5) kernel)")
         head["all_contractions"] = dict(ms_per_step=round(c_ms * scale / psteps, 4), algorithmic_tflops=round(c_fl / (c_ms * scale), 2), executed_tflops=round(c_ex / (c_ms * scale), 2),
                                         vs_f32_mfma_peak=round(c_fl / (c_ms * scale) / FP32_MFMA_PEAK_TFLOPS, 4))
     return {

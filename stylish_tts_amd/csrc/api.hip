@@ -102,7 +102,8 @@ int stts_finalize_weights(stts_ctx* c, int which) {
     // (and on the f32 matrix cores, not the split-fp32 form: latency-bound launches, and per-utterance GRN weights in the style encoder)
     const int saved_prec = c->prec;
     c->prec = PREC_F32;
-    c->pack_x3 = false;
+    static const bool phoneme_x3 = getenv("STTS_PHONEME_X3") && atoi(getenv("STTS_PHONEME_X3")) != 0;  // experiment: the split form for the phoneme-rate contractions too
+    c->pack_x3 = phoneme_x3;
     const int rc = finalize_phoneme(c, static_cast<PhonemeModel*>(c->phoneme.get()), ph);
     c->pack_x3 = true;
     c->prec = saved_prec;

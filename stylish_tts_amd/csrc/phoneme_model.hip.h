@@ -393,6 +393,7 @@ inline int text_style_forward(stts_ctx* c, hipStream_t st, const StyleEncW& W, c
     set_seg(b, 0, U, inter4, 0, B.pw2);
     b.seg[0].W = w2u;
     b.seg[0].W16 = reinterpret_cast<const unsigned short*>(w2u);
+    b.seg[0].w16_plane = 0;  // (per-utterance fp32 copies: no split planes, this contraction stays on the f32 matrix cores)
     b.seg[0].w_utt_stride = (long)B.pw2.npad * B.pw2.kc;
     b.N = sd; b.bias = B.pw2.bias; b.Y = h2; b.ldy = sd; b.R = h; b.ldr = sd;
     STTS_TRY(launch_conv_gemm(st, b, EPI_STORE, B.pw2.npad, s.n_utt, ml));
