@@ -3,7 +3,7 @@
 
     python tests/asan/build_and_run.py [build_dir]
 
-Steps: (1) hipcc --cuda-host-only -fsanitize=address,undefined -c csrc/api.hip (no device code is generated or loaded),
+Steps: (1) hipcc --cuda-host-only -fsanitize=address,undefined -c for every translation unit of the library (no device code is generated or loaded),
 (2) link it with hip_stub.cpp into libstylish_hip_asan.so (the fat-binary symbol the host code references is defined as an
 empty blob), (3) dump the synthetic weights of every inference module to a binary file, (4) run asan_driver on it.
 Exit code 0 = no sanitizer report and every stage accepted its workspace for every shape."""
@@ -21,16 +21,23 @@ def main(build_dir):
     os.makedirs(build_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-O1", "-g", "-std=c++17", "-fPIC"]
-    obj = os.path.join(build_dir, "api_host.o")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-host-only", *san, "-c", os.path.join(ROOT, "stylish_tts_amd", "csrc", "api.hip"), "-o", obj])
-    syms = subprocess.check_output(["nm", "-u", obj], text=True).split()
-    fatbin = [s for s in syms if s.startswith("__hip_fatbin")]
+    # every translation unit of the library (__graft_entry__.UNITS: api.hip + one unit per operand form of the contraction kernels), host side only, in parallel
+    import __graft_entry__ as entry
+
+    objs, procs = [], []
+    for u in entry.UNITS:
+        o = os.path.join(build_dir, u.replace(".hip", "_host.o"))
+        objs.append(o)
+        procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950", "--cuda-host-only", *san, "-c", os.path.join(ROOT, "stylish_tts_amd", "csrc", u), "-o", o]))
+    if any(p.wait() != 0 for p in procs):
+        raise subprocess.CalledProcessError(1, "hipcc --cuda-host-only")
+    fatbin = sorted({s for o in objs for s in subprocess.check_output(["nm", "-u", o], text=True).split() if s.startswith("__hip_fatbin")})
     cxx = os.environ.get("CXX_ASAN", "/opt/rocm/lib/llvm/bin/clang++")  # the same clang, as a plain C++ compiler / linker driver
     stub = os.path.join(build_dir, "hip_stub.o")
     subprocess.check_call([cxx, *san, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", os.path.join(HERE, "hip_stub.cpp"), "-o", stub])
     lib = os.path.join(build_dir, "libstylish_hip_asan.so")
     defsym = [f"-Wl,--defsym={s}=stts_stub_fatbin" for s in fatbin]
-    subprocess.check_call([cxx, "-shared", *san, obj, stub, *defsym, "-o", lib])
+    subprocess.check_call([cxx, "-shared", *san, *objs, stub, *defsym, "-o", lib])
     exe = os.path.join(build_dir, "asan_driver")
     subprocess.check_call([cxx, *san, os.path.join(HERE, "asan_driver.cpp"), lib, f"-Wl,-rpath,{build_dir}", "-o", exe])
 
