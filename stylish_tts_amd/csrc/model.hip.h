@@ -1455,10 +1455,16 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     for (int u = 0; u < s.n_utt; ++u) b64 += ceil_div(s.host[u + 1] - s.host[u], 64);
     fusedx3_rt = b64 > 256 ? 4 : 2;
     const int force = getenv("STTS_WN_X3") ? atoi(getenv("STTS_WN_X3")) : 0;  // tests / tools: 2 / 4 = block shape, -1 = the f32 kernel
-    if (force == 2 || force == 4) fusedx3_rt = force;
+    if (force == 1 || force == 2 || force == 4) fusedx3_rt = force;
     if (force == -1) fusedx3_rt = 0;
   }
-  if (c->prec == PREC_F32 && fused_m == 1 && c->flow[0].fused.ready_x3 && getenv("STTS_WN_X3") && atoi(getenv("STTS_WN_X3")) > 0) fusedx3_rt = atoi(getenv("STTS_WN_X3")) == 4 ? 4 : 2;
+  // small batches (the f32 kernel would run its direct form on 16-row blocks, M = 1): the split kernel on 16-row blocks too
+  if (c->prec == PREC_F32 && fused_m == 1 && c->flow[0].fused.ready_x3) {
+    fusedx3_rt = 1;
+    const int force = getenv("STTS_WN_X3") ? atoi(getenv("STTS_WN_X3")) : 0;
+    if (force == 1 || force == 2 || force == 4) fusedx3_rt = force;
+    if (force == -1) fusedx3_rt = 0;
+  }
   // ... and one launch per COUPLING layer (wn_block_x3_kernel: four WaveNet layers + post + coupling + next pre, h and `out` on chip) with 32 output
   // rows per block (48 computed), 48 (64 computed: what fits the LDS next to the fp32 residual stream) once the 32-row blocks exceed one chip round
   int blockx3_rt = 0;
@@ -1632,6 +1638,9 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
         if (fusedx3_rt == 4) {
           if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
           else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
+        } else if (fusedx3_rt == 1) {
+          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<1, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
+          else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<1, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
         } else {
           if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<2, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
           else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<2, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);

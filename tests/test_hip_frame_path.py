@@ -134,11 +134,11 @@ def test_prior_flow_golden(hip):
     close(cm(mel, 1, 512, 64), g["mel"], what="post_flow")
 
 
-@pytest.mark.parametrize("m", ["1", "2", "4", "16", "x2", "x4", "b3", "b4"])
+@pytest.mark.parametrize("m", ["1", "2", "4", "16", "x1", "x2", "x4", "b3", "b4"])
 def test_prior_flow_fused_wavenet_kernel(hip, weights, m, monkeypatch):
     """wn_fused_kernel (direct form with 16-row blocks / F(2,5) with 32-row blocks / F(4,5) with 64-row blocks; picked by batch
     size in production; "16" = the staged 16-row kernel it replaced for the smallest batches) and wn_fused_x3_kernel (the split-fp32
-    form, "x2" / "x4" = 32- / 64-row blocks, one launch per WaveNet layer: what production runs from ~B = 5 on; "b3" / "b4" = wn_block_x3_kernel, one launch per coupling layer with 32 / 48
+    form, "x1" / "x2" / "x4" = 16- / 32- / 64-row blocks, one launch per WaveNet layer: what production runs; "b3" / "b4" = wn_block_x3_kernel, one launch per coupling layer with 32 / 48
     output rows per block: built and measured, not selected) forced
     on small and ragged inputs: the reference golden, and per-utterance oracle runs for lengths that leave partial
     blocks, one-row tails and utterances shorter than the conv's reach."""
