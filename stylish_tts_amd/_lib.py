@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstylish_hip.so")
+# STTS_LIB: another build of the library next to the product one (diagnostic builds: STTS_BUILD_TAG=_wntrace STTS_HIPCC_FLAGS=-DSTTS_WN_TRACE ...)
+LIB_PATH = os.path.abspath(os.environ["STTS_LIB"]) if os.environ.get("STTS_LIB") else os.path.join(_HERE, "libstylish_hip.so")
 
 
 class ModelDims(C.Structure):

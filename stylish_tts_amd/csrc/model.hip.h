@@ -1635,6 +1635,9 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
           memcpy(fa.seg_inline, s.host, (s.n_utt + 1) * sizeof(int));
         }
         const dim3 fgrid(ceil_div(ml, 16 * fusedx3_rt), s.n_utt);
+#ifdef STTS_WN_TRACE
+        xa.dbg = wn_trace_buffer((f * 4 + i), (long)fgrid.x * fgrid.y);
+#endif
         if (fusedx3_rt == 4) {
           if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
           else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
@@ -1713,7 +1716,7 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
     STTS_HIP(hipGetLastError());
   }
 #ifdef STTS_WN_TRACE
-  if (fused_m) wn_trace_report(st);
+  if (fused_m || fusedx3_rt) wn_trace_report(st);
 #endif
   if (z_flow_out) STTS_HIP(hipMemcpyAsync(z_flow_out, z, R * fh * sizeof(float), hipMemcpyDeviceToDevice, st));
   GemmArgs a = gemm_args(s);

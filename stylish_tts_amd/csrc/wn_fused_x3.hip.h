@@ -18,6 +18,7 @@ namespace stts {
 struct WnFusedX3Args {
   WnFused16Args b;        // W1 .. W4 point to plane 0 of the three-plane fragment arrays
   long p1, p2, p3, p4;    // f32x4 units between two planes of W1 / W2 / W3 / W4
+  long long* dbg;         // per-block phase stamps, written only by a -DSTTS_WN_TRACE build (diagnostics; wn_fused.hip.h's layout)
 };
 
 // B operand planes of four fp32 values -> their slots in the three 16-bit row tiles
@@ -50,6 +51,14 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int nvalid = hi - row0;
+#ifdef STTS_WN_TRACE
+  long long* const dbg_rec = ax.dbg ? ax.dbg + 64 * (long)(blockIdx.x + gridDim.x * blockIdx.y) + 8 * w : nullptr;
+  auto stamp = [&](int i) { if (dbg_rec && lane == 0) dbg_rec[i] = i == 6 || i == 7 ? wall_clock64() : clock64(); };
+  stamp(6);
+#else
+  auto stamp = [](int) {};
+#endif
+  stamp(0);
 
   // ---- phase-1 weight stream: half a tap (2 k-steps x (tanh, sigmoid) x CT tiles, three planes) ahead
   constexpr int T1 = KS * 2 * CT;  // fragments per tap and plane
@@ -94,6 +103,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
     gb[c] = *reinterpret_cast<const f32x4*>(a.gate + (long)utt * a.ld_gate + a.gcol0 + C + ch);
   }
   __syncthreads();
+  stamp(1);
 
   // B operand of the 16x16x32 MFMA from a row tile: lane (row l15, k-group lq) reads 8 consecutive channels of its row
   auto rows_frag = [&](const f32x4* tile, int row, int kstep) { return tile[row * 16 + ((4 * kstep + lq) ^ (row & 15))]; };
@@ -161,6 +171,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   __builtin_amdgcn_sched_barrier(0);
   half1(2 * TAPS - 2, bq0);
   half1(2 * TAPS - 1, bq1);
+  stamp(2);
 
   // ---- phase-2 operands: the res/skip weights of the first two k-steps, bias, the h / out values the epilogue updates
   const f32x4* w2 = reinterpret_cast<const f32x4*>(a.W2) + (size_t)w * KS * (NCT * 64) + lane;
@@ -204,6 +215,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
       put4_x3(As, APL, 16 * rt + l15, (C / NW) * w + 16 * c + 4 * lq, act);
     }
   __syncthreads();
+  stamp(3);
 
   // ---- phase 2: res/skip, K = 128 from LDS; wave w owns columns [16 NCT w, 16 NCT (w + 1))
   f32x4 acc2[RT][NCT];
@@ -227,6 +239,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   };
   half2(0, cq0);
   half2(1, cq1);
+  stamp(4);
 
   if constexpr (!LAST) {
 #pragma unroll
@@ -239,6 +252,8 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
       for (int rt = 0; rt < RT; ++rt)
         if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(dst + (long)(row0 + 16 * rt + l15) * C + col) = old[rt][c] + (acc2[rt][c] + bv[c]);
     }
+    stamp(5);
+    stamp(7);
     return;
   } else {
     // ---- tail: post + reverse coupling (+ the next block's pre); wave w: mean / log-std tiles of channels [16 w, 16 w + 16)
@@ -300,7 +315,11 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
       if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(a.Z + (long)(row0 + 16 * rt + l15) * a.ldz + a.zcol0 + cc) = z1;
       put4_x3(Hs, HPL, 16 * rt + l15, cc, z1);  // the conv tile is long dead: rows [0, ROWS) x channels [0, 64) of it now hold z1
     }
-    if (a.tail < 2) return;
+    if (a.tail < 2) {
+      stamp(5);
+      stamp(7);
+      return;
+    }
     __syncthreads();
     f32x4 acc4[RT][2];
 #pragma unroll
@@ -321,6 +340,8 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
         if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(a.Hpre + (long)(row0 + 16 * rt + l15) * C + 32 * w + 16 * c + 4 * lq) = acc4[rt][c] + hb[c];
+    stamp(5);
+    stamp(7);
   }
 }
 
