@@ -438,8 +438,8 @@ def roofline_leg(ctx: Ctx, args, model, frame_step, ms_per_step, traffic, traffi
         "event_calibration": {"timed_step_ms": round(ms_per_step, 4), "plain_step_gpu_ms": round(plain_ms, 4), "sum_of_event_timed_kernels_ms": round(raw_all, 4), "scale": round(scale, 4),
                               "frac_uncalibrated": round(d_fl / d_ms / peak, 4) if d_ms > 0 else 0.0,
                               "note": "durations x scale, scale = min(1, timed step / sum of the event-timed kernel durations): the instrumented pass (an event pair on every launch, "
-                                      "no side stream) cannot describe a step longer than the one that was timed; rocprofv3's un-overlapped kernel durations (profiles/) sum to the same "
-                                      "un-scaled figure"},
+                                      "no side stream) cannot describe a step longer than the one that was timed; rocprofv3 traces the step WITH its side stream, where the kernels that "
+                                      "overlap each other run 5-10 % longer each: its per-kernel durations (profiles/, tools/summarize_r04.py) sum to more than the step"},
         "traffic": traffic, "traffic_note": traffic_note,
         "launches_per_step": d_n // psteps, "avg_launch_ms": round(d_ms * scale / max(d_n, 1), 5),
         "algorithmic_gflop_per_step": round(c_fl / psteps, 2), "executed_gflop_per_step": round(c_ex / psteps, 2),
