@@ -1383,6 +1383,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   // the shared resource (block-timeline trace, profiles/).  When the last round would be mostly empty (288 tiles = 1.125
   // rounds for a 3.5 s batch of 8), the whole rounds run as they are and the REMAINDER row tiles run as a second launch
   // with K cut over up to 8 blocks (+ reduce pass over those rows only): 1 + ~1/8 rounds instead of 2.
+  bool x3 = false;  // split fp32 (decided below, before any plan is made)
   struct Plan {
     long full_rt = 0, rem_rt = 0;  // row tiles in the plain launch / in the split-K remainder launch
     int rem_ksp = 1;
@@ -1394,7 +1395,10 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
     const long whole = blocks / kCUs;
     p.full_rt = rt;
     p.cost = std::ceil((double)blocks / kCUs);
-    if (splittable && a.seg_host && !a.capacity && whole >= 1 && blocks % kCUs != 0) {  // (the remainder launch needs exact host offsets)
+    // (split fp32: whole launches.  Its blocks are 1.5 x shorter, and a remainder launch + its reduce pass then cost more than the partly empty last round:
+    //  cfg2 3.58 -> 3.475 ms per step without the 12 remainder launches and 11 reduce passes of the Winograd plane contractions; STTS_X3_REM=1 brings them back)
+    static const bool x3_rem = getenv("STTS_X3_REM") && atoi(getenv("STTS_X3_REM")) != 0;
+    if ((!x3 || x3_rem) && splittable && a.seg_host && !a.capacity && whole >= 1 && blocks % kCUs != 0) {  // (the remainder launch needs exact host offsets)
       const long full_rt = whole * kCUs / mt, rem_blocks = (rt - full_rt) * mt;
       const int ksp = (int)std::min<long>(8, std::min<long>(iters / 4, kCUs / std::max<long>(rem_blocks, 1)));
       if (ksp >= 2 && full_rt > 0) {
@@ -1412,7 +1416,7 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   };
   const long blocks128 = mt * row_tiles(128);
   // split fp32: fp32 call, every segment carries the three bf16 planes of its weight, epilogue with a split instantiation
-  bool x3 = a.prec == PREC_F32 && x3_enabled() && (epi == EPI_STORE || epi == EPI_PRIOR);
+  x3 = a.prec == PREC_F32 && x3_enabled() && (epi == EPI_STORE || epi == EPI_PRIOR);
   for (int i = 0; i < a.nseg; ++i) x3 = x3 && a.seg[i].W16 != nullptr && a.seg[i].w16_plane > 0 && 6 * a.seg[i].w16_plane + 2L * 128 * a.seg[i].ntaps * a.seg[i].kc < (1L << 32);
   // pre-split activation planes (x16 on an fp32 call): store epilogue, no input affine, no block split-K (the callers know: run_winograd)
   if (a.x16 && a.prec == PREC_F32) {
