@@ -1451,9 +1451,15 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
   // weight stream per row); small batches (16-row blocks win there) stay on the f32 kernel's direct form
   int fusedx3_rt = 0;
   if (c->prec == PREC_F32 && fused_m != 0 && fused_m != 1 && c->flow[0].fused.ready_x3) {
-    long b64 = 0;
-    for (int u = 0; u < s.n_utt; ++u) b64 += ceil_div(s.host[u + 1] - s.host[u], 64);
-    fusedx3_rt = b64 > 256 ? 4 : 2;
+    long b64 = 0, b32 = 0;
+    for (int u = 0; u < s.n_utt; ++u) {
+      b64 += ceil_div(s.host[u + 1] - s.host[u], 64);
+      b32 += ceil_div(s.host[u + 1] - s.host[u], 32);
+    }
+    // one block per CU is resident: a launch takes ceil(blocks / 256) rounds.  Fitted to 3-s batches of 8 .. 32 (us per launch): 32-row blocks 4.5 + 17.5 per
+    // round, 64-row blocks (twice the matrix work per block for one weight stream) 1.5 + 29.5 per round.  B = 8: 22 vs 31; B = 10 .. 16: 40 vs 31;
+    // B = 20 / 24: 57 vs 60; B = 32: 74 vs 60 - the measured optimum at every one of them
+    fusedx3_rt = 1.5 + 29.5 * ceil_div((int)b64, 256) < 4.5 + 17.5 * ceil_div((int)b32, 256) ? 4 : 2;
     const int force = getenv("STTS_WN_X3") ? atoi(getenv("STTS_WN_X3")) : 0;  // tests / tools: 2 / 4 = block shape, -1 = the f32 kernel
     if (force == 1 || force == 2 || force == 4) fusedx3_rt = force;
     if (force == -1) fusedx3_rt = 0;
