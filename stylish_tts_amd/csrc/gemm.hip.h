@@ -1467,7 +1467,14 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
   STTS_CHECK(!((tile == 14 || tile == 15) && (a.prec == PREC_F32 || epi != EPI_STORE)), "conv_gemm: tiles 14 / 15 are for 16-bit operand store launches");
   STTS_CHECK(!((tile >= 16 && tile <= 18) && (a.prec == PREC_F32 || epi != EPI_STORE || !a.x16)), "conv_gemm: tiles 16 - 18 are for 16-bit activation rows, store epilogue");
   STTS_CHECK((tile != 14 && tile != 16) || npad % 256 == 0, "conv_gemm: tiles 14 / 16 need cout padded to 256");
-  if (x3 && !a.x16 && force_tile == 0 && (tile == 5 || tile == 6) && row_tiles(256) * mt >= 640) {
+  if (x3 && !a.x16 && force_tile == 0 && (tile == 5 || tile == 6)) {
+    static const int x3_tile = getenv("STTS_X3_TILE") ? atoi(getenv("STTS_X3_TILE")) : 0;  // experiments: 5 / 6 / 22 for every large split-fp32 launch
+    if (x3_tile == 5 || x3_tile == 6 || x3_tile == 22) {
+      tile = x3_tile;
+      plan = Plan();
+    }
+  }
+  if (x3 && !a.x16 && force_tile == 0 && (tile == 5 || tile == 6) && row_tiles(256) * mt >= 640 && !getenv("STTS_X3_TILE")) {
     // split fp32, launches of at least 2.5 chip rounds of 256-row tiles: 8 waves of 64 x 64 (half the weight staging per row, 12 instead of 18 fragment
     // reads per 24 MFMAs).  B = 64 x 3 s: every layer 8-12 % faster than the 128 x 128 tile (decoder conv2 648 -> 595 us, output conv 3 637 -> 3 342);
     // B = 24: the 1536- and 1024-wide layers (1 080 / 720 blocks) gain, the 512-wide ones (360 blocks = 1.4 rounds) would lose and keep the 128-row tile
