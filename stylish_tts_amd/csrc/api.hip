@@ -47,6 +47,9 @@ void stts_ctx_destroy(stts_ctx* c) {
     if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
     if (kv.second.join) (void)hipEventDestroy(kv.second.join);
     if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+    if (kv.second.fork2) (void)hipEventDestroy(kv.second.fork2);
+    if (kv.second.join2) (void)hipEventDestroy(kv.second.join2);
+    if (kv.second.stream2) (void)hipStreamDestroy(kv.second.stream2);
   }
   delete c;
 }

@@ -82,6 +82,8 @@ struct GemmArgs {
   const float* xaff;
   int ld_xaff;
   float xaff_slope;       // negative-side slope of that activation (0.2: LeakyReLU; 1: a pure per-channel scale / shift, e.g. GRN folded into pwconv2's staging)
+  bool xaff_scale_only;   // the shift row is all zeros, the slope 1 and no input column is padding (kc == channels): x' = x * scale, one multiply per element
+                          // (split-fp32 single-segment launches have an instantiation for it, XAFF = 2; elsewhere the general form runs - same result)
   long long* dbg;         // block-timeline records (only written when built with -DSTTS_GEMM_TRACE; tools/gemm_bench.py)
   const float* zeros;     // >= 16 bytes of zeros in global memory (source of out-of-utterance rows for the LDS-DMA path)
   int ksplit;             // > 1: grid.z = n_utt * ksplit, block (u, ks) contracts a 1/ksplit slice of K into partial[ks]
@@ -193,7 +195,7 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4 a, const f32x4 b, const f32
 // KSPLIT = 2: two wave groups share every staged tile and split its 32-channel chunk in halves (kk 0,1 / kk 2,3); their
 // partial accumulators are summed through LDS before the epilogue.  Doubles the waves per SIMD for launches that only
 // have ~one 128x128 tile per CU (B = 8: every 512-channel layer), which is where the matrix pipe otherwise idles.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, bool XAFF = false, bool MSEG = true,
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, int KSPLIT = 1, bool GLDS = false, int PREC = PREC_F32, int XAFF = 0, bool MSEG = true,
           bool X16 = false>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(const GemmArgs a) {
   static_assert(!(XAFF && GLDS), "the input affine lives on the register staging path");
@@ -241,7 +243,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-      gy = (unsigned)tot;
+      // (every lane holds the same sum, but a cross-lane read is divergent to the compiler: without the readfirstlane the tile indices, the K-loop
+      //  cursor and the segment fields all lived in VGPRs, and every cursor advance was a v_cmp + s_and_saveexec branch that cut the K loop into basic blocks)
+      gy = (unsigned)__builtin_amdgcn_readfirstlane(tot);
       if ((unsigned)by >= gy) return;
     }
     const unsigned gx = gridDim.x, nwg = gx * gy * gridDim.z;
@@ -289,7 +293,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       base += __shfl(incl, 63, 64);
     }
     if (!done) return;  // a row tile beyond the batch's last one: the host grid is an upper bound when the offsets live on the device
-    by = local;
+    utt = __builtin_amdgcn_readfirstlane(utt);  // (wave-uniform values behind cross-lane reads: scalar registers from here on, see above)
+    by = __builtin_amdgcn_readfirstlane(local);
   } else {
     utt = bz / ksplit;
     ks = bz % ksplit;
@@ -397,7 +402,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       const int r = X16 ? idp >> 2 : idx >> 3, sl = X16 ? idp & 3 : idx & 7;
       const int rel = (hot ? 0 : rel0) + r + shift;
       const int crel = min(max(rel, 0), len - 1);
-      const unsigned off = X16 ? (unsigned)((crel * g_ldx + sl * 8) * 2) : (unsigned)((crel * g_ldx + sl * 4) * 4);
+      // (24-bit multiply: full rate, v_mul_lo_u32 is quarter rate; rows and row strides are far below 2^24, byte offsets below 2^31 - host-checked)
+      const unsigned rowoff = __umul24((unsigned)crel, (unsigned)g_ldx);
+      const unsigned off = X16 ? (rowoff + sl * 8) * 2 : (rowoff + sl * 4) * 4;
       if constexpr (X16 && X3) rs.x[i] = *reinterpret_cast<const f32x4*>(xb + (long)pl * g_xplane * 2 + off);
       else
       rs.x[i] = *reinterpret_cast<const f32x4*>(xb + off);
@@ -409,17 +416,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       rs.aff = s == 0;
       const float* ap = a.xaff + (long)utt * 2 * a.ld_xaff + (rs.aff ? chunk * 32 + (tid & 7) * 4 : 0);
       rs.sc = *reinterpret_cast<const f32x4*>(ap);
-      rs.sh = *reinterpret_cast<const f32x4*>(ap + a.ld_xaff);
+      if constexpr (XAFF == 1) rs.sh = *reinterpret_cast<const f32x4*>(ap + a.ld_xaff);
     }
     // advance: TAP is the inner index, so the taps of one 32-channel chunk re-read (almost) the same rows of X
     // back to back and hit L1/L2; channel-inner order re-streamed the whole X tile per tap from the fabric (rocprof
     // FETCH_SIZE was ~10x the compulsory bytes).  Scalar selects only; the last tile is re-loaded when the cursor
     // would run off the end.
-    const bool wrapt1 = tap + 1 >= g_ntaps;
-    const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);  // segment finished
-    const bool last = wrapt && (!MSEG || s + 1 >= nseg);
+    // (bitwise, not short-circuit: the compiler turned `&&` into a scalar branch around the chunk update, one more block boundary in the loop)
+    const int w1 = tap + 1 >= g_ntaps, wk = (chunk + 1) * 32 >= g_kc;
+    const bool wrapt1 = w1 != 0;
+    const bool wrapt = (w1 & wk) != 0;  // segment finished
+    const bool last = ((w1 & wk) & (MSEG ? (int)(s + 1 >= nseg) : 1)) != 0;
     tap = last ? tap : (wrapt1 ? 0 : tap + 1);
-    chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
+    chunk = last ? chunk : (wrapt ? 0 : chunk + w1);
     if constexpr (MSEG) {  // (single-segment launches are compiled without this branch: the K loop is one basic block)
       if (wrapt && !last) {  // uniform, taken at most twice per kernel
         ++s;
@@ -436,7 +445,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
   auto xin = [&](const RegSet& rs, int i) {  // the value of X load i that enters LDS
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 v = rs.x[i];
-    if constexpr (XAFF) {
+    if constexpr (XAFF == 2) {  // scale only (GRN in front of pwconv2): single segment, so every tile takes it
+      static_assert(XAFF != 2 || !MSEG, "the scale-only input affine is instantiated for single-segment launches");
+      v = v * rs.sc;
+    } else if constexpr (XAFF == 1) {
       f32x4 t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1246,8 +1258,8 @@ inline void launch_cfg(hipStream_t st, const GemmArgs& a, int epi, int npad, int
       }
       if constexpr (!GL) {
         if (a.xaff) {
-          if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true, false>), grid, block, st, e0, e1, a);
-          else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, true, true>), grid, block, st, e0, e1, a);
+          if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, 1, false>), grid, block, st, e0, e1, a);
+          else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, GL, PR, 1, true>), grid, block, st, e0, e1, a);
           break;
         }
         if (a.nseg == 1) {
@@ -1281,8 +1293,9 @@ inline void launch_cfg_x3(hipStream_t st, const GemmArgs& a, int epi, int npad, 
   if (epi == EPI_PRIOR) {
     if constexpr (BM / WM >= 64) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_PRIOR, KS, false, PREC_X3>), grid, block, st, e0, e1, a);
   } else if (a.xaff) {
-    if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, true, false>), grid, block, st, e0, e1, a);
-    else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, true, true>), grid, block, st, e0, e1, a);
+    if (a.nseg == 1 && a.xaff_scale_only) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, 2, false>), grid, block, st, e0, e1, a);
+    else if (a.nseg == 1) STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, 1, false>), grid, block, st, e0, e1, a);
+    else STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, 1, true>), grid, block, st, e0, e1, a);
   } else if (a.nseg == 1) {
     STTS_LAUNCH_TIMED((conv_gemm_f32<BM, BN, WM, WN, EPI_STORE, KS, false, PREC_X3, false, false>), grid, block, st, e0, e1, a);
   } else {

@@ -149,6 +149,9 @@ struct stts_ctx {
   struct SideLane {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    // second side stream: short independent contractions inside a stage (the decoder blocks' learned shortcuts, stts::SideWork)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t fork2 = nullptr, join2 = nullptr;
   };
   std::map<hipStream_t, SideLane> side_lanes;
   std::mutex side_mu;
@@ -1035,6 +1038,13 @@ inline long fold_rows() {
   static const long v = getenv("STTS_FOLD_ROWS") ? atol(getenv("STTS_FOLD_ROWS")) : 2500;
   return v;
 }
+// A second stream for a contraction that is independent of the launches around it (run_adain_block: the learned 1x1 shortcut next to conv1), with the
+// fork / join events that order it against the caller's stream and an output buffer of its own ([rows, cout]).
+struct SideWork {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  float* out = nullptr;
+};
 struct AdainStats {
   float* in = nullptr;   // statistics of x for norm1 (layout of adain_partial_kernel, round_up(cin, 32) columns)
   bool in_ready = false;
@@ -1050,7 +1060,9 @@ struct AdainStats {
 inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, const float* style_out, int ld_style, const float* x, int ldx,
                            float* y, int ldy, float* act1, float* hbuf, float* act2, float* ss, int force_tile = 0, WinoScratch* wino = nullptr,
                            unsigned short* xs16 = nullptr, bool xs16_ready = false, unsigned short* y16 = nullptr, int ldy16 = 0,
-                           AdainStats* stats = nullptr, PendingReduce* pend_in = nullptr, PendingReduce* pend_out = nullptr) {
+                           AdainStats* stats = nullptr, PendingReduce* pend_in = nullptr, PendingReduce* pend_out = nullptr, const SideWork* side = nullptr) {
+  // side (fp32 Winograd branch, learned shortcut): the 1x1 shortcut contraction - it reads the block's input only - runs on side->stream next to conv1's three
+  // launches (whose plane contraction fills the chip 1.25 times and whose transforms leave the matrix cores idle) instead of between conv1 and conv2.
   // pend_in / pend_out (small batches, fold path): x's first columns may still be the split-K partial sums of the contraction that produced them
   // (pend_in: finished by norm1's statistics launch, which also writes them to x); conv2's own reduce pass is left to the caller's next consumer
   // (pend_out).  Without them every contraction finishes its own output.
@@ -1124,6 +1136,20 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   a.bias = B.conv1.bias;
   a.Y = hbuf;
   a.ldy = B.cout;
+  auto shortcut = [&](hipStream_t sst, float* out) -> int {
+    GemmArgs g = gemm_args(s);
+    set_seg(g, 0, x, ldx, 0, B.sc);
+    g.N = B.cout; g.bias = nullptr; g.Y = out; g.ldy = B.cout;
+    return launch_conv_gemm(sst, g, EPI_STORE, B.sc.npad, s.n_utt, ml, 0);
+  };
+  const bool sc_side = side && side->stream && side->out && wino1 && wino2 && B.sc.W && !gemm_profiler().on;
+  if (sc_side) {  // x is complete in st's order here; side->out was last read by the previous block's conv2, which st has queued before this event
+    STTS_HIP(hipEventRecord(side->fork, st));
+    STTS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+    const int rc = shortcut(side->stream, side->out);
+    STTS_HIP(hipEventRecord(side->join, side->stream));  // (recorded whatever rc is: st joins below or at the caller's error path via stream order)
+    if (rc) { (void)hipStreamWaitEvent(st, side->join, 0); return rc; }
+  }
   if (wino1) {
     // large batches: conv1 (k = 3) in Winograd F(6,3) form, 8 instead of 18 multiplies per 6 outputs (winograd.hip.h); AdaIN + LeakyReLU ride
     // in its input transform (an elementwise, bandwidth-bound kernel: there the affine is free, unlike in the K loop)
@@ -1179,11 +1205,12 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
   if (wino2) {
     const float* res = x;
     int ld_res = ldx;
-    if (B.sc.W) {  // act1 is free again (conv1 has consumed it): the shortcut's output lives there
-      GemmArgs g = gemm_args(s);
-      set_seg(g, 0, x, ldx, 0, B.sc);
-      g.N = B.cout; g.bias = nullptr; g.Y = act1; g.ldy = B.cout;
-      STTS_TRY(launch_conv_gemm(st, g, EPI_STORE, B.sc.npad, s.n_utt, ml, 0));
+    if (B.sc.W && sc_side) {
+      STTS_HIP(hipStreamWaitEvent(st, side->join, 0));
+      res = side->out;
+      ld_res = B.cout;
+    } else if (B.sc.W) {  // act1 is free again (conv1 has consumed it): the shortcut's output lives there
+      STTS_TRY(shortcut(st, act1));
       res = act1;
       ld_res = B.cout;
     }
@@ -1209,7 +1236,7 @@ inline int run_adain_block(hipStream_t st, const Seg& s, const AdainBlockW& B, c
 // stage: Decoder.forward (models/decoder.py:47-60)
 // ------------------------------------------------------------------------------------------------
 inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const float* asr, int ld_asr, const float* pitch, const float* energy,
-                           const float* style, float* x_out, int ld_x, Arena& ws) {
+                           const float* style, float* x_out, int ld_x, Arena& ws, const SideWork* side_lane = nullptr) {
   const stts_model_dims& d = c->d;
   const long R = s.rows();
   const int ccat = d.dec_hidden + d.dec_residual + 2, ldcat = c->dec[1].kcin;  // 578 -> 608 (640 in the 16-bit modes): the packed input width
@@ -1231,6 +1258,8 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   // conv1 of every block in Winograd form once the batch is large enough to be throughput-bound (B = 1: 35 vs 30 us)
   WinoScratch wino;
   if (R > fold_rows() && c->dec[1].w1.ready) wino.p = ws.get<float>(wino_scratch_floats(s, c->dec[1].w1));
+  // the learned shortcuts' outputs when they run on the side lane (run_adain_block; carved whenever the Winograd branch may run, so the size does not depend on the caller's streams)
+  float* sc_out = wino.p && c->dec[1].sc.W ? ws.get<float>(R * d.dec_hidden) : nullptr;
   // 16-bit modes, large batches: rounded copies of the blocks' inputs for the learned shortcuts, ping-pong like xa / xb: a block's
   // conv2 epilogue writes the hidden columns of the next block's copy, the constant columns (asr_res, F0, N) are rounded once
   const bool x16 = R >= rows16_threshold() && c->prec != PREC_F32 && d.dec_hidden % 8 == 0;
@@ -1294,18 +1323,35 @@ inline int decoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
   float* nxt = xb;
   unsigned short* cur16 = xs16a;
   unsigned short* nxt16 = xs16b;
-  for (int i = 1; i <= 4; ++i) {
-    float* dst = i == 4 ? x_out : nxt;
-    const int ldd = i == 4 ? ld_x : ldcat;
-    STTS_TRY(const_columns());
-    stats.in = ss_in;
-    stats.in_ready = stats.out_ready;  // (the previous block's conv2 - conv_gemm16_kernel's epilogue or the fp32 Winograd output transform - left the statistics of its output)
-    stats.out = i == 4 ? nullptr : ss_in;
-    STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat,
-                             use_stats ? &stats : nullptr, &pend, &pend));
-    std::swap(cur, nxt);
-    std::swap(cur16, nxt16);
+  // Measured (3-s utterances, same box, alternated): B = 16: 5.82 -> 5.74 ms per step (+1.4 %); B = 8: 3.505 -> 3.52 (-0.5 %), B = 4: 2.39 -> 2.42 (-1.3 %): below
+  // ~12 000 rows the two cross-queue waits per block cost what the overlap gains, and the shortcuts stay on the caller's stream (STTS_SC_SIDE_MIN_ROWS).
+  static const long sc_side_min_rows = getenv("STTS_SC_SIDE_MIN_ROWS") ? atol(getenv("STTS_SC_SIDE_MIN_ROWS")) : 12000;
+  SideWork side;
+  if (side_lane && sc_out && R >= sc_side_min_rows) {
+    side = *side_lane;
+    side.out = sc_out;
   }
+  auto blocks = [&]() -> int {
+    for (int i = 1; i <= 4; ++i) {
+      float* dst = i == 4 ? x_out : nxt;
+      const int ldd = i == 4 ? ld_x : ldcat;
+      STTS_TRY(const_columns());
+      stats.in = ss_in;
+      stats.in_ready = stats.out_ready;  // (the previous block's conv2 - conv_gemm16_kernel's epilogue or the fp32 Winograd output transform - left the statistics of its output)
+      stats.out = i == 4 ? nullptr : ss_in;
+      STTS_TRY(run_adain_block(st, s, c->dec[i], sty, lds, cur, ldcat, dst, ldd, act1, hbuf, act2, ss, 0, &wino, cur16, x16, i == 4 ? nullptr : nxt16, ldcat,
+                               use_stats ? &stats : nullptr, &pend, &pend, side.stream ? &side : nullptr));
+      std::swap(cur, nxt);
+      std::swap(cur16, nxt16);
+    }
+    return 0;
+  };
+  const int rc = blocks();
+  if (rc && side.stream) {  // an error path may have left a shortcut running on the side lane: the caller's stream must not outrun it (it reads x and writes the workspace)
+    (void)hipEventRecord(side.join, side.stream);
+    (void)hipStreamWaitEvent(st, side.join, 0);
+  }
+  if (rc) return rc;
   return pending_finish(st, &pend);  // the last block's output has no AdaIN behind it
 }
 
@@ -1892,6 +1938,8 @@ inline int vocoder_body(stts_ctx* c, hipStream_t st, const Seg& s, const float* 
       b.xaff = w2u;
       b.ld_xaff = B.pw2.kc;
       b.xaff_slope = 1.0f;
+      static const bool no_scale_only = getenv("STTS_XAFF_GENERAL") != nullptr;  // experiments: the general scale / shift / slope form
+      b.xaff_scale_only = B.pw2.kc == inter && !no_scale_only;  // (no pad column: every staged value is a written one)
     } else {
     launch_scale_weight(st, dim3(128, s.n_utt), B.pw2.prec, B.pw2.W, gscale, inter, B.grn_gamma, w2u, B.pw2.npad, B.pw2.kc);
     b.seg[0].W = w2u;
@@ -1955,7 +2003,7 @@ inline int vocoder_forward(stts_ctx* c, hipStream_t st, const Seg& s, const floa
     } else {
       STTS_TRY(prior_conv(c, st, s, 0, har_spec, ld_har, headA, &wino, har16));
       STTS_TRY(prior_conv(c, st, s, 1, har_phase, ld_har, headP, &wino, har16));
-    }
+      }
   }
   return vocoder_body(c, st, s, mel, ld_mel, style, headA, headP, audio, logamp_out, phase_out, ld_lp, ws);
 }
@@ -2013,6 +2061,9 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
         STTS_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         STTS_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
         STTS_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+        STTS_HIP(hipStreamCreateWithFlags(&l.stream2, hipStreamNonBlocking));
+        STTS_HIP(hipEventCreateWithFlags(&l.fork2, hipEventDisableTiming));
+        STTS_HIP(hipEventCreateWithFlags(&l.join2, hipEventDisableTiming));
       }
       lane = l;
     }
@@ -2032,7 +2083,9 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
     STTS_HIP(hipEventRecord(lane.join, lane.stream));
     if (rc == 0) {
       auto main_part = [&]() -> int {
-        { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
+        SideWork sw;
+        sw.stream = lane.stream2; sw.fork = lane.fork2; sw.join = lane.join2;
+        { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a, &sw)); }
         { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a, mel16, ldm16)); }
         return 0;
       };
@@ -2054,7 +2107,7 @@ inline int frame_path(stts_ctx* c, hipStream_t st, const Seg& s, const float* as
     } else {
       STTS_TRY(prior_conv(c, st, s, 0, hs, ldh, headA, &wino, nullptr, h16 != 0));
       STTS_TRY(prior_conv(c, st, s, 1, hp, ldh, headP, &wino, nullptr, h16 != 0));
-    }
+      }
   }
   { Arena a = stage(); STTS_TRY(decoder_forward(c, st, s, asr, ld_asr, pitch, energy, style, x, dh, a)); }
   { Arena a = stage(); STTS_TRY(prior_flow_forward(c, st, s, x, dh, style, prior_noise, mel, dh, nullptr, nullptr, a, mel16, ldm16)); }

@@ -283,10 +283,12 @@ __device__ __forceinline__ FftTw fft_load_tw(const double2* __restrict__ tw, int
   t.w2048l = tw[lane];
   return t;
 }
+// (workgroup scope = an s_waitcnt lgkmcnt(0) on both sides of every exchange; a wave's LDS operations complete in order, so wavefront scope - no
+//  instruction at all - is what the memory model asks for, and it measured the same; the wait is kept as the form that does not lean on that)
 __device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 template <typename T2, bool INV>
 __device__ __forceinline__ void fft1024_wave(T2 (&v)[16], T2* buf, const FftTw& tw, int lane) {
@@ -469,6 +471,16 @@ __device__ __forceinline__ void sincos_unit(float p, float& sn, float& cs) {
 // The Hermitian spectrum makes the output real, so the 2048-point inverse runs as ONE 1024-point complex transform:
 //   E[k] = (X[k] + conj(X[H-k]))/2 ,  O[k] = (X[k] - conj(X[H-k]))/2 * e^{+2 pi i k/N} ,  Z[k] = E[k] + i O[k]  (H = N/2)
 //   z = IFFT_H(Z) / H ;  x[2n] = Re z[n], x[2n+1] = Im z[n]
+// NO PACKED-FP32 INSTRUCTIONS in this kernel (round 4).  Compiled with them (456 v_pk_add / v_pk_mul / v_pk_fma_f32 in the butterflies) the kernel
+// returned DIFFERENT frames for the same rows whenever blocks of the split-fp32 contractions (bf16 MFMA + their own v_pk_* split arithmetic, 96+ KB of
+// LDS: an istft block fits beside one on a CU) ran on other streams at the same time: two back-to-back launches on identical, host-verified inputs
+// differed in 16-point groups of single frames (values off by 1e-3 .. 1e-1, never garbage), with the stream idle on both sides of each launch and with
+// s_waitcnt lgkmcnt(0) around every LDS exchange; alone on the GPU, or next to the f32-MFMA contractions, never.  Without packed ops: 0 differences in
+// 1 400 concurrent launches (tools/debug/stage_race.py, tests/test_hip_concurrency.py).  The forward transform (fp64, no packed fp32) never showed it.
+// Cost: none measurable (33 us per launch at B = 8 either way).  DESIGN.md section 5d.
+#ifndef STTS_ISTFT_PACKED_FP32
+__attribute__((target("no-packed-fp32-ops")))
+#endif
 __global__ void __launch_bounds__(64 * kFftWaves) istft_frames_kernel(const float* __restrict__ logamp, const float* __restrict__ phase, int ld,
                                                                       const int* __restrict__ seg_off, const float* __restrict__ hann,
                                                                       const double2* __restrict__ twiddle, float* __restrict__ yw) {
