@@ -1453,6 +1453,10 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       // 128x128 vs 128x64 tiles by that cost (576 blocks of 128x64 cost three half-sized rounds)
       const Plan p5 = plan_for(128, 1.0), p6 = plan_for(64, 1.03);
       tile = p5.cost <= p6.cost ? 5 : 6;
+      // split fp32, short K (at most 24 iterations: the 1 x 1 convs over 512-768 channels): the prologue and epilogue of a block are a fifth of its life, and
+      // two co-resident 128 x 64 blocks hide them behind each other's K loop (B = 8, per launch inside the step: pwconv1 94.2 -> 87.3 us, the small
+      // 1 x 1 convs 19.0 -> 16.9 / 18.7 -> 15.7; deep K keeps the 128 x 128 tile: pwconv2 85.7 vs 87.4)
+      if (x3 && iters <= 24 && !a.xaff) tile = 6;
       plan = tile == 5 ? p5 : p6;
       // one 128x128 tile per CU (B = 8: every 512-channel layer): two K-groups of 8 waves share each staged tile, which
       // keeps the matrix pipes busier than 8 waves do (118 vs 125.5 us) and beats cutting K over two blocks plus the
@@ -1487,7 +1491,11 @@ inline int launch_conv_gemm(hipStream_t st, const GemmArgs& a, int epi, int npad
       plan = Plan();
     }
   }
-  if (x3 && !a.x16 && force_tile == 0 && (tile == 5 || tile == 6) && row_tiles(256) * mt >= 640 && !getenv("STTS_X3_TILE")) {
+  // (... or a launch of at least 440 such blocks that fills its last chip round to 80 %: the output convs' Winograd planes at B = 8 are 480 blocks = 1.9
+  //  rounds, 212.6 -> 193.0 and 206.5 -> 184.9 us per conv; 360 blocks = 1.4 rounds lose, pwconv1 94 -> 99)
+  const long blocks22 = row_tiles(256) * mt;
+  const bool fills22 = blocks22 >= 640 || (blocks22 >= 440 && (blocks22 % kCUs == 0 || blocks22 % kCUs >= kCUs * 4 / 5));
+  if (x3 && !a.x16 && force_tile == 0 && (tile == 5 || tile == 6) && fills22 && !getenv("STTS_X3_TILE")) {
     // split fp32, launches of at least 2.5 chip rounds of 256-row tiles: 8 waves of 64 x 64 (half the weight staging per row, 12 instead of 18 fragment
     // reads per 24 MFMAs).  B = 64 x 3 s: every layer 8-12 % faster than the 128 x 128 tile (decoder conv2 648 -> 595 us, output conv 3 637 -> 3 342);
     // B = 24: the 1536- and 1024-wide layers (1 080 / 720 blocks) gain, the 512-wide ones (360 blocks = 1.4 rounds) would lose and keep the 128-row tile
