@@ -669,11 +669,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(lds + b * STG16 + pl * PLANE + inst * 64), 16, 0, 0);
         }
-        const bool wrapt1 = tap + 1 >= g_ntaps;
-        const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
-        const bool last = wrapt && (!MSEG || s + 1 >= nseg);
+        const int w1 = tap + 1 >= g_ntaps, wk = (chunk + 1) * 32 >= g_kc;  // (bitwise: see the register path's cursor)
+        const bool wrapt1 = w1 != 0;
+        const bool wrapt = (w1 & wk) != 0;
+        const bool last = ((w1 & wk) & (MSEG ? (int)(s + 1 >= nseg) : 1)) != 0;
         tap = last ? tap : (wrapt1 ? 0 : tap + 1);
-        chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
+        chunk = last ? chunk : (wrapt ? 0 : chunk + w1);
         if constexpr (MSEG) {
           if (wrapt && !last) {
             ++s;
@@ -742,11 +743,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
                                            (__attribute__((address_space(3))) void*)(lds + b * (BN + BM) * 8 + inst * 64), 16, 0, 0);
         }
         // advance the cursor (same order as the register path)
-        const bool wrapt1 = tap + 1 >= g_ntaps;
-        const bool wrapt = wrapt1 && ((chunk + 1) * 32 >= g_kc);
-        const bool last = wrapt && (s + 1 >= nseg);
+        const int w1 = tap + 1 >= g_ntaps, wk = (chunk + 1) * 32 >= g_kc;
+        const bool wrapt1 = w1 != 0;
+        const bool wrapt = (w1 & wk) != 0;
+        const bool last = ((w1 & wk) & (int)(s + 1 >= nseg)) != 0;
         tap = last ? tap : (wrapt1 ? 0 : tap + 1);
-        chunk = last ? chunk : (wrapt ? 0 : (wrapt1 ? chunk + 1 : chunk));
+        chunk = last ? chunk : (wrapt ? 0 : chunk + w1);
         if (wrapt && !last) {
           ++s;
           const GemmSeg& n = s == 1 ? a.seg[1] : a.seg[2];
@@ -847,7 +849,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       frag_read(it & 1, 1, fB);
       frag_mma(fA);
       if (!ablate(4)) lstore(nset, (it + 1) & 1);
-      if (!ablate(8)) gload(nset);
+      if (!ablate(8)) gload(nset);  // (issued behind the barrier instead, under the second half's MFMAs: 3-4 % slower on every shape, 73.0 -> 76.4 us on the decoder's conv2)
       if (!ablate(2)) __syncthreads();  // (waits for this wave's LDS traffic first: its reads of this tile have landed before anybody overwrites the stage)
       frag_read((it + 1) & 1, 0, fA);  // (after the last tile: a stale stage, read and dropped)
       frag_mma(fB);
