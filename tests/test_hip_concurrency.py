@@ -64,3 +64,25 @@ def test_stages_are_bit_stable_under_concurrent_streams(cfg, precision):
             for f in [pool.submit(lane, k) for k in range(workers)]:
                 bad += f.result()
     assert not bad, f"{len(bad)} stage outputs changed under concurrency: {sorted(set(bad))[:12]}"
+
+
+@pytest.mark.parametrize("batch", [8, 16])
+def test_frame_path_with_its_side_streams_is_bit_stable_run_to_run(cfg, batch):
+    """The benchmarked configuration runs the source / STFT / prior-conv chain on a side stream beside the decoder (B = 8 x 3 s) and, from 12 000 rows on, the decode blocks'
+    learned shortcuts on a second one (B = 16): the same inputs must give the same bits every time."""
+    from stylish_tts_amd import modules, synth
+    from stylish_tts_amd.runtime import Segments
+
+    mods = modules.build_inference_modules(cfg, synthetic_seed=0)
+    eng = mods["speech_predictor"].engine
+    for m in mods.values():
+        m.engine
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    seg = Segments([960] * batch, eng.device)
+    R = seg.rows
+    inp = [dev(synth.normal("fs.asr", (R, cfg.inter_dim))), dev(np.abs(synth.normal("fs.f0", (R,))) * 60 + 120), dev(synth.normal("fs.en", (R,))),
+           dev(synth.normal("fs.sty", (batch, cfg.style_dim))), dev(synth.normal("fs.pn", (R, 128))), dev(synth.normal("fs.sn", (R * 75,))), dev(synth.uniform("fs.ph", (1,)))]
+    ref = eng.frame_path(seg, *inp, batch_scope=False).clone()
+    for i in range(25):
+        y = eng.frame_path(seg, *inp, batch_scope=False)
+        assert torch.equal(y, ref), f"run {i}: {int((y != ref).sum())} samples differ from the first run"
