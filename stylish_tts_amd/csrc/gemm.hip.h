@@ -850,6 +850,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
       frag_mma(fA);
       if (!ablate(4)) lstore(nset, (it + 1) & 1);
       if (!ablate(8)) gload(nset);  // (issued behind the barrier instead, under the second half's MFMAs: 3-4 % slower on every shape, 73.0 -> 76.4 us on the decoder's conv2)
+#ifndef STTS_X3_NO_SGB
+      // Issue pattern for the half in front of the barrier (6 TR TC MFMAs, the split of the next tile, its LDS writes, the fetch after it): one MFMA, then
+      // seven vector instructions, twelve times over - the scheduler's own order left the MFMAs in bunches of three to nine.  Measured (B = 8, per launch):
+      // decoder conv2 73.1 -> 72.1 us, output conv 537 -> 519, Winograd planes 81.0 -> 79.9; with LDS / memory slots in the pattern as well: slower (75.5);
+      // 5 or 8 instead of 7: no gain.  (The same pattern placed behind the barrier - where the second half has no vector work to spread - cost 4-5 %.)
+#pragma unroll
+      for (int g = 0; g < 6 * TR * TC; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // VALU
+      }
+#endif
       if (!ablate(2)) __syncthreads();  // (waits for this wave's LDS traffic first: its reads of this tile have landed before anybody overwrites the stage)
       frag_read((it + 1) & 1, 0, fA);  // (after the last tile: a stale stage, read and dropped)
       frag_mma(fB);
@@ -861,6 +872,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64 * KSPLIT) conv_gemm_f32(
         if (!ablate(4)) lstore(nset, (it + 1) & 1);
         if (!ablate(8)) gload(nset);
         mma_step16(it & 1, 1);
+#ifndef STTS_X3_NO_SGB
+        if constexpr (X3) {
+          // split fp32, tiles without the fragment pipeline: one MFMA, then this tile's share of the iteration's vector instructions (~25 of addressing + ~30 per X
+          // load of split arithmetic, over 12 TR TC MFMAs) + 1.  128 x 256 tile: decoder conv2 110.3 -> 102.6 us, Winograd planes 71.5 -> 69.4, output conv
+          // 470 -> 446; 128 x 64 tile 77.4 -> 76.9; one or two more per group: back to the unpatterned times
+          constexpr int NM = 12 * TR * TC, NV = (25 + 30 * XL + NM - 1) / NM + 1;
+#pragma unroll
+          for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+          }
+        }
+#endif
       } else {
         mma_step16(it & 1, kg);
         lstore(nset, (it + 1) & 1);
