@@ -215,14 +215,24 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < N; ++j) v += t.At[i][j] * m[j];
         float* y = Y + (long)(lo + row) * ldy + n4;
+        if (n4 + 4 <= Nout) {  // whole quad (every layer of the model: cout % 4 == 0; leading dimensions are multiples of 4, checked by run_winograd): 16-byte residual load and store
+          f32x4 e;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (n4 + c < Nout) {
-            float e = act_apply(v[c], act);
-            if (R) e += R[(long)(lo + row) * ldr + n4 + c];
-            e *= alpha;
-            y[c] = e;
-            o[i][c] = e;
+          for (int c = 0; c < 4; ++c) e[c] = act_apply(v[c], act);
+          if (R) e += *reinterpret_cast<const f32x4*>(R + (long)(lo + row) * ldr + n4);
+          e *= alpha;
+          *reinterpret_cast<f32x4*>(y) = e;
+          o[i] = e;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (n4 + c < Nout) {
+              float e = act_apply(v[c], act);
+              if (R) e += R[(long)(lo + row) * ldr + n4 + c];
+              e *= alpha;
+              y[c] = e;
+              o[i][c] = e;
+            }
           }
         }
       }
