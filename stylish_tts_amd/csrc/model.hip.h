@@ -1690,16 +1690,22 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
 #ifdef STTS_WN_TRACE
         xa.dbg = wn_trace_buffer((f * 4 + i), (long)fgrid.x * fgrid.y);
 #endif
-        if (fusedx3_rt == 4) {
-          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
-          else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<4, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
-        } else if (fusedx3_rt == 1) {
-          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<1, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
-          else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<1, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
-        } else {
-          if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<2, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
-          else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<2, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);
-        }
+        static const int x3_waves = getenv("STTS_WN_X3_WAVES") ? atoi(getenv("STTS_WN_X3_WAVES")) : 0;  // experiments: 4 / 8 waves per block (0: the rule below)
+        const bool eight = x3_waves ? x3_waves == 8 : true;
+#define STTS_WNX3(RT_)                                                                                                                  \
+  do {                                                                                                                                   \
+    if (eight) {                                                                                                                         \
+      if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<RT_, true, 2 * kWnWaves>), fgrid, dim3(128 * kWnWaves), st, e0, e1, xa);        \
+      else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<RT_, false, 2 * kWnWaves>), fgrid, dim3(128 * kWnWaves), st, e0, e1, xa);             \
+    } else {                                                                                                                             \
+      if (i == 3) STTS_LAUNCH_TIMED((wn_fused_x3_kernel<RT_, true>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);                       \
+      else STTS_LAUNCH_TIMED((wn_fused_x3_kernel<RT_, false>), fgrid, dim3(64 * kWnWaves), st, e0, e1, xa);                            \
+    }                                                                                                                                    \
+  } while (0)
+        if (fusedx3_rt == 4) STTS_WNX3(4);
+        else if (fusedx3_rt == 1) STTS_WNX3(1);
+        else STTS_WNX3(2);
+#undef STTS_WNX3
       }
       else if (fused_m) {
         auto launch = [&](auto mtag) {

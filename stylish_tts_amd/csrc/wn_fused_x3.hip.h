@@ -3,8 +3,10 @@
 // `out` tile, the coupled half of z, and every weight - is the exact sum of three bf16 terms, and a product is formed from its six largest
 // bf16 x bf16 cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Nothing is rounded to 16 bits.
 //
-// Structure = wn_fused16_kernel's (wn_fused16.hip.h): a block owns 16 RT rows and all 256 gate channels, 4 waves (one per SIMD), wave w
-// owns the tanh and sigmoid tiles of channels [32 w, 32 w + 32); the k = 5 conv in its DIRECT form (five row-shifted reads of one LDS tile;
+// Structure = wn_fused16_kernel's (wn_fused16.hip.h): a block owns 16 RT rows and all 256 gate channels; the fragment arrays are packed for 4 waves, packed wave w
+// owning the tanh and sigmoid tiles of channels [32 w, 32 w + 32).  The kernel runs with EIGHT waves (two per SIMD; template parameter NW): two waves share a packed
+// wave's slice, one tile of 16 channels each - same arrays, same LDS tiles, same bits out, each fragment still fetched by exactly one wave; the second wave per SIMD
+// hides part of the weight stream's and the gate's latency: 23.6 -> 22.6 us per launch at B = 8, flow 0.756 -> 0.723 ms, -4..5 % at B = 16 .. 64 (STTS_WN_X3_WAVES=4|8); the k = 5 conv in its DIRECT form (five row-shifted reads of one LDS tile;
 // the f32 kernel's F(2,5) Toom-Cook form saves 40 % of the multiplies, the split form 62 % of the matrix-pipe cycles of a direct f32 conv);
 // weights come straight from global memory in MFMA-fragment order, three planes per matrix, HALF A TAP (2 k-steps x 4 tiles x 3 planes =
 // 24 KB per wave) ahead of the MFMAs that consume them; products are oriented D^T = W x A^T so a lane holds four consecutive channels.
@@ -33,10 +35,13 @@ __device__ __forceinline__ void put4_x3(f32x4* tile, int plane, int row, int ch,
 
 typedef unsigned u32x4_x3 __attribute__((ext_vector_type(4)));
 
-template <int RT, bool LAST>
-__global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax) {
+// NW = 4 (one wave per SIMD) or 8: two waves share the slice of the fragment arrays that was packed for one of four - wave w = 2 pw + sub owns tile(s) `sub` of packed wave pw's
+// tiles in every phase - so the arrays, the LDS tiles and the results are the same; the weight stream per block too (each fragment is fetched by one wave).
+template <int RT, bool LAST, int NW = kWnWaves>
+__global__ void __launch_bounds__(64 * NW) wn_fused_x3_kernel(const WnFusedX3Args ax) {
   const WnFused16Args& a = ax.b;
-  constexpr int ROWS = 16 * RT, C = kWnC, NW = kWnWaves, CT = C / NW / 16, NCT = LAST ? CT : 2 * CT, TAPS = 5, PAD = 2;
+  constexpr int ROWS = 16 * RT, C = kWnC, PW = kWnWaves, SUB = NW / PW, CTP = C / PW / 16, CT = CTP / SUB, NCTP = LAST ? CTP : 2 * CTP, NCT = NCTP / SUB, TAPS = 5, PAD = 2;
+  static_assert(NW == PW || NW == 2 * PW, "4 or 8 waves");
   constexpr int KS = C / 32;                   // 32-channel k-steps of a 128-channel contraction
   constexpr int HROWS = ROWS + 2 * PAD;
   constexpr int HPL = HROWS * 16, APL = ROWS * 16;  // f32x4 slots of one plane
@@ -49,6 +54,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   const int row0 = lo + blockIdx.x * ROWS;
   if (row0 >= hi) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pw = w / SUB, sub = w % SUB;  // packed wave whose slice this wave shares, and which part of it
   const int l15 = lane & 15, lq = lane >> 4;
   const int nvalid = hi - row0;
 #ifdef STTS_WN_TRACE
@@ -61,21 +67,22 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   stamp(0);
 
   // ---- phase-1 weight stream: half a tap (2 k-steps x (tanh, sigmoid) x CT tiles, three planes) ahead
-  constexpr int T1 = KS * 2 * CT;  // fragments per tap and plane
-  constexpr int H1 = T1 / 2;       // ... per half tap
-  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.W1) + (size_t)w * TAPS * (T1 * 64) + lane;
+  constexpr int T1 = KS * 2 * CTP;  // packed fragments per tap and plane (of one packed wave)
+  constexpr int H1P = T1 / 2;       // ... per half tap
+  constexpr int H1 = H1P / SUB;     // this wave's share: index (tt * 2 + h) * CT + c  <->  packed (tt * 2 + h) * CTP + sub * CT + c
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.W1) + (size_t)pw * TAPS * (T1 * 64) + lane;
   f32x4 bq0[3][H1], bq1[3][H1];
   auto load1 = [&](f32x4(&dst)[3][H1], int half) {  // half = 2 tap + (k-steps 2, 3)
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int j = 0; j < H1; ++j) dst[p][j] = w1[p * ax.p1 + (size_t)(half * H1 + j) * 64];
+      for (int j = 0; j < H1; ++j) dst[p][j] = w1[p * ax.p1 + (size_t)(half * H1P + (j / CT) * CTP + sub * CT + j % CT) * 64];
   };
   load1(bq0, 0);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- prologue: h rows -> the three planes of the LDS tile (rows outside the utterance are the conv's zero padding)
-  for (int idx = tid; idx < HROWS * 16; idx += 256) {
+  for (int idx = tid; idx < HROWS * 16; idx += 64 * NW) {
     const int r = idx >> 4, sl = idx & 15;
     const int row = row0 + r - PAD;
     const bool ok = row >= lo && row < hi;
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   f32x4 ba[CT], bb[CT], ga[CT], gb[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const int ch = (C / NW) * w + 16 * c + 4 * lq;
+    const int ch = (C / PW) * pw + 16 * (sub * CT + c) + 4 * lq;
     ba[c] = *reinterpret_cast<const f32x4*>(a.b1 + ch);
     bb[c] = *reinterpret_cast<const f32x4*>(a.b1 + C + ch);
     ga[c] = *reinterpret_cast<const f32x4*>(a.gate + (long)utt * a.ld_gate + a.gcol0 + ch);
@@ -174,12 +181,12 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   stamp(2);
 
   // ---- phase-2 operands: the res/skip weights of the first two k-steps, bias, the h / out values the epilogue updates
-  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.W2) + (size_t)w * KS * (NCT * 64) + lane;
-  auto load2 = [&](f32x4(&dst)[3][2 * NCT], int half) {
+  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.W2) + (size_t)pw * KS * (NCTP * 64) + lane;
+  auto load2 = [&](f32x4(&dst)[3][2 * NCT], int half) {  // own index tt * NCT + c  <->  packed tt * NCTP + sub * NCT + c
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int j = 0; j < 2 * NCT; ++j) dst[p][j] = w2[p * ax.p2 + (size_t)(half * 2 * NCT + j) * 64];
+      for (int j = 0; j < 2 * NCT; ++j) dst[p][j] = w2[p * ax.p2 + (size_t)(half * 2 * NCTP + (j / NCT) * NCTP + sub * NCT + j % NCT) * 64];
   };
   f32x4 cq0[3][2 * NCT], cq1[3][2 * NCT];
   load2(cq0, 0);
@@ -187,7 +194,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   f32x4 bv[NCT], old[RT][NCT];
 #pragma unroll
   for (int c = 0; c < NCT; ++c) {
-    const int n = 16 * NCT * w + 16 * c + 4 * lq;
+    const int n = 16 * NCTP * pw + 16 * (sub * NCT + c) + 4 * lq;
     bv[c] = *reinterpret_cast<const f32x4*>(a.b2 + n);
     const bool to_h = !LAST && n < C;
     const int col = (!LAST && n >= C) ? n - C : n;
@@ -212,7 +219,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
         const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.885390082f * va[i]) + 1.0f);
         act[i] = th * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * vb[i]));
       }
-      put4_x3(As, APL, 16 * rt + l15, (C / NW) * w + 16 * c + 4 * lq, act);
+      put4_x3(As, APL, 16 * rt + l15, (C / PW) * pw + 16 * (sub * CT + c) + 4 * lq, act);
     }
   __syncthreads();
   stamp(3);
@@ -244,7 +251,7 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
   if constexpr (!LAST) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-      const int n = 16 * NCT * w + 16 * c + 4 * lq;
+      const int n = 16 * NCTP * pw + 16 * (sub * NCT + c) + 4 * lq;
       const bool to_h = n < C;
       const int col = to_h ? n : n - C;
       float* dst = to_h ? a.Hout : a.Out;
@@ -256,64 +263,70 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
     stamp(7);
     return;
   } else {
-    // ---- tail: post + reverse coupling (+ the next block's pre); wave w: mean / log-std tiles of channels [16 w, 16 w + 16)
-    const f32x4* w3 = reinterpret_cast<const f32x4*>(a.W3) + (size_t)w * KS * (2 * 64) + lane;
-    f32x4 pq[3][KS][2];
+    // ---- tail: post + reverse coupling (+ the next block's pre); packed wave pw: mean / log-std tiles of channels [16 pw, 16 pw + 16).  With eight waves the first
+    // wave of each pair runs it (a 16-channel tile pair per packed wave: nothing to split), the other one only keeps the barriers and writes its part of `out`.
+    const bool tw = sub == 0;
+    constexpr int KS4 = KS / 2;  // K = 64
+    f32x4 pq[3][KS][2], rq[3][KS4][2];
+    f32x4 pm = {0.f, 0.f, 0.f, 0.f}, ps = pm, zold[RT];
+    f32x4 hb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int cc = 16 * pw + 4 * lq;
+    if (tw) {
+      const f32x4* w3 = reinterpret_cast<const f32x4*>(a.W3) + (size_t)pw * KS * (2 * 64) + lane;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int t = 0; t < KS; ++t) {
-        pq[p][t][0] = w3[p * ax.p3 + (t * 2 + 0) * 64];
-        pq[p][t][1] = w3[p * ax.p3 + (t * 2 + 1) * 64];
-      }
-    const int cc = 16 * w + 4 * lq;
-    const f32x4 pm = *reinterpret_cast<const f32x4*>(a.b3m + cc), ps = *reinterpret_cast<const f32x4*>(a.b3s + cc);
-    f32x4 zold[RT];
+        for (int t = 0; t < KS; ++t) {
+          pq[p][t][0] = w3[p * ax.p3 + (t * 2 + 0) * 64];
+          pq[p][t][1] = w3[p * ax.p3 + (t * 2 + 1) * 64];
+        }
+      pm = *reinterpret_cast<const f32x4*>(a.b3m + cc);
+      ps = *reinterpret_cast<const f32x4*>(a.b3s + cc);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) zold[rt] = *reinterpret_cast<const f32x4*>(a.Z + (long)(row0 + 16 * rt + l15) * a.ldz + a.zcol0 + cc);
+      for (int rt = 0; rt < RT; ++rt) zold[rt] = *reinterpret_cast<const f32x4*>(a.Z + (long)(row0 + 16 * rt + l15) * a.ldz + a.zcol0 + cc);
+    }
     __syncthreads();  // every wave has finished reading the gated activations
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) put4_x3(As, APL, 16 * rt + l15, 16 * NCT * w + 16 * c + 4 * lq, old[rt][c] + (acc2[rt][c] + bv[c]));
+      for (int rt = 0; rt < RT; ++rt) put4_x3(As, APL, 16 * rt + l15, 16 * NCTP * pw + 16 * (sub * NCT + c) + 4 * lq, old[rt][c] + (acc2[rt][c] + bv[c]));
     __syncthreads();
-    f32x4 acc3[RT][2];
+    if (tw) {
+      f32x4 acc3[RT][2];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc3[rt][0] = acc3[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < RT; ++rt) acc3[rt][0] = acc3[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < KS; ++t) {
+      for (int t = 0; t < KS; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 av[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) av[p] = rows_frag(As + p * APL, 16 * rt + l15, t);
+          acc3[rt][0] = mma6(pq[0][t][0], pq[1][t][0], pq[2][t][0], av, acc3[rt][0]);
+          acc3[rt][1] = mma6(pq[0][t][1], pq[1][t][1], pq[2][t][1], av, acc3[rt][1]);
+        }
+      }
+      if (a.tail > 1) {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(a.W4) + (size_t)pw * KS4 * (2 * 64) + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int t = 0; t < KS4; ++t) {
+            rq[p][t][0] = w4[p * ax.p4 + (t * 2 + 0) * 64];
+            rq[p][t][1] = w4[p * ax.p4 + (t * 2 + 1) * 64];
+          }
+        hb[0] = *reinterpret_cast<const f32x4*>(a.b4 + 32 * pw + 4 * lq);
+        hb[1] = *reinterpret_cast<const f32x4*>(a.b4 + 32 * pw + 16 + 4 * lq);
+      }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        f32x4 av[3];
+        const f32x4 mm = acc3[rt][0] + pm, ls = acc3[rt][1] + ps;
+        f32x4 z1;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) av[p] = rows_frag(As + p * APL, 16 * rt + l15, t);
-        acc3[rt][0] = mma6(pq[0][t][0], pq[1][t][0], pq[2][t][0], av, acc3[rt][0]);
-        acc3[rt][1] = mma6(pq[0][t][1], pq[1][t][1], pq[2][t][1], av, acc3[rt][1]);
+        for (int i = 0; i < 4; ++i) z1[i] = (zold[rt][i] - mm[i]) * __expf(-ls[i]);  // flow.py:209
+        if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(a.Z + (long)(row0 + 16 * rt + l15) * a.ldz + a.zcol0 + cc) = z1;
+        put4_x3(Hs, HPL, 16 * rt + l15, cc, z1);  // the conv tile is long dead: rows [0, ROWS) x channels [0, 64) of it now hold z1
       }
-    }
-    constexpr int KS4 = KS / 2;  // K = 64
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(a.W4) + (size_t)w * KS4 * (2 * 64) + lane;
-    f32x4 rq[3][KS4][2];
-    f32x4 hb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (a.tail > 1) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int t = 0; t < KS4; ++t) {
-          rq[p][t][0] = w4[p * ax.p4 + (t * 2 + 0) * 64];
-          rq[p][t][1] = w4[p * ax.p4 + (t * 2 + 1) * 64];
-        }
-      hb[0] = *reinterpret_cast<const f32x4*>(a.b4 + 32 * w + 4 * lq);
-      hb[1] = *reinterpret_cast<const f32x4*>(a.b4 + 32 * w + 16 + 4 * lq);
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const f32x4 mm = acc3[rt][0] + pm, ls = acc3[rt][1] + ps;
-      f32x4 z1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) z1[i] = (zold[rt][i] - mm[i]) * __expf(-ls[i]);  // flow.py:209
-      if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(a.Z + (long)(row0 + 16 * rt + l15) * a.ldz + a.zcol0 + cc) = z1;
-      put4_x3(Hs, HPL, 16 * rt + l15, cc, z1);  // the conv tile is long dead: rows [0, ROWS) x channels [0, 64) of it now hold z1
     }
     if (a.tail < 2) {
       stamp(5);
@@ -321,25 +334,27 @@ __global__ void __launch_bounds__(256) wn_fused_x3_kernel(const WnFusedX3Args ax
       return;
     }
     __syncthreads();
-    f32x4 acc4[RT][2];
+    if (tw) {
+      f32x4 acc4[RT][2];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc4[rt][0] = acc4[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < RT; ++rt) acc4[rt][0] = acc4[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < KS4; ++t) {
+      for (int t = 0; t < KS4; ++t) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        f32x4 av[3];
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 av[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) av[p] = rows_frag(Hs + p * HPL, 16 * rt + l15, t);
-        acc4[rt][0] = mma6(rq[0][t][0], rq[1][t][0], rq[2][t][0], av, acc4[rt][0]);
-        acc4[rt][1] = mma6(rq[0][t][1], rq[1][t][1], rq[2][t][1], av, acc4[rt][1]);
+          for (int p = 0; p < 3; ++p) av[p] = rows_frag(Hs + p * HPL, 16 * rt + l15, t);
+          acc4[rt][0] = mma6(rq[0][t][0], rq[1][t][0], rq[2][t][0], av, acc4[rt][0]);
+          acc4[rt][1] = mma6(rq[0][t][1], rq[1][t][1], rq[2][t][1], av, acc4[rt][1]);
+        }
       }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(a.Hpre + (long)(row0 + 16 * rt + l15) * C + 32 * pw + 16 * c + 4 * lq) = acc4[rt][c] + hb[c];
     }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        if (16 * rt + l15 < nvalid) *reinterpret_cast<f32x4*>(a.Hpre + (long)(row0 + 16 * rt + l15) * C + 32 * w + 16 * c + 4 * lq) = acc4[rt][c] + hb[c];
     stamp(5);
     stamp(7);
   }
