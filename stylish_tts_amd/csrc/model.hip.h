@@ -1690,8 +1690,8 @@ inline int prior_flow_forward(stts_ctx* c, hipStream_t st, const Seg& s, const f
 #ifdef STTS_WN_TRACE
         xa.dbg = wn_trace_buffer((f * 4 + i), (long)fgrid.x * fgrid.y);
 #endif
-        static const int x3_waves = getenv("STTS_WN_X3_WAVES") ? atoi(getenv("STTS_WN_X3_WAVES")) : 0;  // experiments: 4 / 8 waves per block (0: the rule below)
-        const bool eight = x3_waves ? x3_waves == 8 : true;
+        static const int x3_waves = getenv("STTS_WN_X3_WAVES") ? atoi(getenv("STTS_WN_X3_WAVES")) : 8;  // experiments: 4 waves per block (default: eight, wn_fused_x3.hip.h)
+        const bool eight = x3_waves != 4;
 #define STTS_WNX3(RT_)                                                                                                                  \
   do {                                                                                                                                   \
     if (eight) {                                                                                                                         \
