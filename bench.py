@@ -617,6 +617,7 @@ def run_cfg3(ctx: Ctx, args, steps: int, warmup: int):
         state["waves"] = outs[-1]
     assert all(bool(torch.isfinite(x).all()) for x in state["waves"])
     # stage split (one extra call, events on the caller's stream): phoneme-rate part = everything before the frame path
+    syn.stage_times(toks, noise)  # (the caller's own lane may not have run yet when the batches went through map()'s lanes: its workspaces are sized by this call)
     t = syn.stage_times(toks, noise)
     utts = ctx.world * B * steps
     audio_seconds = ctx.world * steps * sum(frames) * 300 / SR
